@@ -1,0 +1,178 @@
+/*
+ * vfi_hip.h -- C ABI of libvfi_hip.so, the MI355X (gfx950) implementation of the
+ * DAIN / VFIDKR frame-synthesis hot path.
+ *
+ * One entry point per function the reference's pybind11 extension modules
+ * export.  No torch types cross this boundary: device
+ * pointers, sizes, element strides and a HIP stream.  The torch extension
+ * modules in csrc/shim/ (same module and function names as the reference's)
+ * and the ctypes loader in the package are both thin callers of this ABI.
+ *
+ * Conventions (kept from the reference bindings unless stated):
+ *  - tensors are float32, NCHW, innermost (w) stride 1; `*_s` arguments are the
+ *    batch / channel / row strides IN ELEMENTS (int64: a 196-channel 4K tensor
+ *    overflows the reference's 32-bit offsets for batch >= 2);
+ *  - all pointers are DEVICE pointers valid on the device `stream` belongs to;
+ *  - calls are asynchronous: kernels are enqueued on `stream`, nothing syncs;
+ *  - return value: 0 = success, 1 = shape/stride problem (the reference
+ *    bindings' silent `return 1`), VFI_ERR_LAUNCH = a HIP launch failed (the
+ *    reference bindings raise AT_ERROR("CUDA call failed") for it);
+ *  - the my_package ops expect the CALLER to zero-fill outputs / counts / grads
+ *    (FilterInterpolationLayer.py:34, FlowProjectionLayer.py:35-36); the
+ *    forward kernels here write every output element, so forward outputs need
+ *    no zero fill, but `count`/`output` of the projections and every grad*
+ *    buffer of a backward MUST arrive zeroed exactly as in the reference.
+ */
+#ifndef VFI_HIP_H
+#define VFI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFI_OK          0
+#define VFI_ERR_SHAPE   1
+#define VFI_ERR_LAUNCH  (-2)
+
+typedef void* vfi_stream_t;           /* hipStream_t */
+
+/* strides of one NCHW tensor, in elements; w stride is 1 by contract */
+typedef struct vfi_strides {
+    int64_t b, c, h;
+} vfi_strides;
+
+/* library / build identification: "vfi_hip <version> gfx950" */
+const char* vfi_version(void);
+
+/* ---- filterinterpolation_cuda ------------------------------------------------
+ * replaces FilterInterpolationLayer_gpu_forward_ori / _backward_ori
+ * (filterinterpolation_cuda.cc:537-606, 608-687).  filter_channels = input3.size(1);
+ * filter_size = (int)sqrt((float)filter_channels) as the binding computes it.
+ * output uses input1's strides (the binding checks they are equal, cc:582-583). */
+int vfi_filterinterp_forward_ori(const float* input1, const float* input2, const float* input3,
+                                 float* output,
+                                 int batch, int channel, int h, int w, int filter_channels,
+                                 vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                 vfi_stream_t stream);
+int vfi_filterinterp_backward_ori(const float* input1, const float* input2, const float* input3,
+                                  const float* gradoutput,
+                                  float* gradinput1, float* gradinput2, float* gradinput3,
+                                  int batch, int channel, int h, int w, int filter_channels,
+                                  vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                  vfi_stream_t stream);
+
+/* deformable-kernel variants (filterinterpolation_cuda.cc:11-92, 191-272, 374-447).
+ * variant: 0 = FilterInterpolationLayer_gpu_forward (4 inputs, fs in {4,6}),
+ *          1 = ..._forward_deforconv, 2 = ..._forward_nofilterwithdeforconv
+ *              (input3 is the 2*fs*fs offset field, input4 unused/NULL).
+ * Documented divergence: the reference reads out of bounds when a displaced tap
+ * leaves the image; here the four bilinear corners are clamped to the image. */
+#define VFI_DEFOR_OFFSET   0
+#define VFI_DEFOR_REGION   1
+#define VFI_DEFOR_NOFILTER 2
+int vfi_filterinterp_forward_defor(int variant,
+                                   const float* input1, const float* input2, const float* input3,
+                                   const float* input4, float* output,
+                                   int batch, int channel, int h, int w, int filter_size,
+                                   vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                   vfi_stream_t stream);
+
+/* ---- flowprojection_cuda -----------------------------------------------------
+ * replaces FlowProjectionLayer_gpu_forward / _backward (flowprojection_cuda.cc:9-57, 59-114).
+ * count [B,1,H,W] and output [B,2,H,W] must arrive zero-filled. */
+int vfi_flowprojection_forward(const float* input1, float* count, float* output,
+                               int batch, int h, int w, int fillhole,
+                               vfi_strides s1, vfi_strides sc,
+                               vfi_stream_t stream);
+int vfi_flowprojection_backward(const float* input1, const float* count, const float* gradoutput,
+                                float* gradinput1,
+                                int batch, int h, int w,
+                                vfi_strides s1, vfi_strides sc,
+                                vfi_stream_t stream);
+
+/* ---- depthflowprojection_cuda ------------------------------------------------
+ * replaces DepthFlowProjectionLayer_gpu_forward / _backward
+ * (depthflowprojection_cuda.cc:10-68, 70-139). */
+int vfi_depthflowprojection_forward(const float* input1, const float* input2,
+                                    float* count, float* output,
+                                    int batch, int h, int w, int fillhole,
+                                    vfi_strides s1, vfi_strides s2, vfi_strides sc,
+                                    vfi_stream_t stream);
+int vfi_depthflowprojection_backward(const float* input1, const float* input2,
+                                     const float* count, const float* output,
+                                     const float* gradoutput,
+                                     float* gradinput1, float* gradinput2,
+                                     int batch, int h, int w,
+                                     vfi_strides s1, vfi_strides s2, vfi_strides sc,
+                                     vfi_stream_t stream);
+
+/* ---- interpolation_cuda / interpolationch_cuda -------------------------------
+ * replaces Interpolation[Ch]Layer_gpu_forward / _backward (interpolation_cuda.cc:10-60,
+ * 63-121).  The C==3 restriction of `interpolation_cuda` lives in its shim. */
+int vfi_interpolation_forward(const float* input1, const float* input2, float* output,
+                              int batch, int channel, int h, int w,
+                              vfi_strides s1, vfi_strides s2,
+                              vfi_stream_t stream);
+int vfi_interpolation_backward(const float* input1, const float* input2, const float* gradoutput,
+                               float* gradinput1, float* gradinput2,
+                               int batch, int channel, int h, int w,
+                               vfi_strides s1, vfi_strides s2,
+                               vfi_stream_t stream);
+
+/* ---- separableconv_cuda ------------------------------------------------------
+ * replaces SeparableConvLayer_gpu_forward / _backward (separableconv_cuda.cc:10-87, 88-174).
+ * h, w are input1's; input2/input3/output are [B, fs | C, h-fs+1, w-fs+1]. */
+int vfi_separableconv_forward(const float* input1, const float* input2, const float* input3,
+                              float* output,
+                              int batch, int channel, int h, int w, int filter_size,
+                              vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so,
+                              vfi_stream_t stream);
+int vfi_separableconv_backward(const float* input1, const float* input2, const float* input3,
+                               const float* gradoutput,
+                               float* gradinput1, float* gradinput2, float* gradinput3,
+                               int batch, int channel, int h, int w, int filter_size,
+                               vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so,
+                               vfi_stream_t stream);
+
+/* ---- separableconvflow_cuda --------------------------------------------------
+ * replaces SeparableConvFlowLayer_gpu_forward / _backward (separableconvflow_cuda.cc:9-102,
+ * 103-199).  input1 is only shape-checked by the reference and is not passed. */
+int vfi_separableconvflow_forward(const float* input2, const float* input3, float* flow_output,
+                                  int batch, int h, int w, int filter_size,
+                                  vfi_strides s2, vfi_strides s3, vfi_strides so,
+                                  vfi_stream_t stream);
+int vfi_separableconvflow_backward(const float* input2, const float* input3,
+                                   const float* gradflow_output,
+                                   float* gradinput2, float* gradinput3,
+                                   int batch, int h, int w, int filter_size,
+                                   vfi_strides s2, vfi_strides s3, vfi_strides so,
+                                   vfi_stream_t stream);
+
+/* ---- correlation_cuda --------------------------------------------------------
+ * replaces correlation_cuda.forward / .backward (correlation_cuda.cc:8-85, 87-165).
+ * Inputs and outputs are DENSE NCHW (the reference kernels ignore strides).
+ * The padded NHWC repack buffers rInput1/rInput2 of the reference are not
+ * needed by these kernels; the shim still resizes and zero-fills them so a
+ * caller that inspects them sees the reference's shapes.
+ * vfi_correlation_output_dims reproduces correlation_cuda.cc:23-36. */
+int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
+                                int stride1, int stride2,
+                                int* out_channels, int* out_h, int* out_w);
+int vfi_correlation_forward(const float* input1, const float* input2, float* output,
+                            int batch, int channel, int h, int w,
+                            int pad_size, int kernel_size, int max_displacement,
+                            int stride1, int stride2,
+                            vfi_stream_t stream);
+int vfi_correlation_backward(const float* input1, const float* input2, const float* gradoutput,
+                             float* gradinput1, float* gradinput2,
+                             int batch, int channel, int h, int w,
+                             int pad_size, int kernel_size, int max_displacement,
+                             int stride1, int stride2,
+                             vfi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFI_HIP_H */

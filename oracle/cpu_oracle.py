@@ -1,0 +1,208 @@
+"""ctypes binding of oracle/libvfi_oracle.so (numpy in, numpy out).
+
+TEST INFRASTRUCTURE ONLY (see vfi_oracle.h).  Every function takes and returns
+dense float32 NCHW numpy arrays and mirrors one reference op:
+
+  filterinterp_ori_fwd/bwd   filterinterpolation_cuda_kernel.cu:2692-3125
+  filterinterp_defor_fwd     filterinterpolation_cuda_kernel.cu:29-426, 1353-1496, 2070-2191
+  flowproj_fwd/bwd           flowprojection_cuda_kernel.cu:29-301
+  depthflowproj_fwd/bwd      depthflowprojection_cuda_kernel.cu:29-341
+  interp_fwd/bwd             interpolation_cuda_kernel.cu:29-202
+  sepconv_fwd/bwd            separableconv_cuda_kernel.cu:29-135
+  sepconvflow_fwd/bwd        separableconvflow_cuda_kernel.cu:29-173
+  correlation_fwd/bwd        correlation_cuda_kernel.cu:47-334
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvfi_oracle.so")
+_lib = None
+
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.c_int
+
+
+def build(force=False):
+    """Compile libvfi_oracle.so with the committed Makefile (gcc)."""
+    src = os.path.join(_HERE, "vfi_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_F)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _check(err, what):
+    if err != 0:
+        raise RuntimeError("oracle %s returned %d" % (what, err))
+
+
+def filterinterp_ori_fwd(img, flow, filt, fmad=0, nthreads=1):
+    img, flow, filt = _f32(img), _f32(flow), _f32(filt)
+    B, C, H, W = img.shape
+    assert flow.shape == (B, 2, H, W) and filt.shape[0] == B and filt.shape[2:] == (H, W)
+    out = np.zeros_like(img)
+    _check(lib().vfi_oracle_filterinterp_ori_fwd(_p(img), _p(flow), _p(filt), _p(out), B, C, H, W,
+                                                 filt.shape[1], int(fmad), int(nthreads)), "filterinterp_ori_fwd")
+    return out
+
+
+def filterinterp_ori_bwd(img, flow, filt, gout, fmad=0):
+    img, flow, filt, gout = _f32(img), _f32(flow), _f32(filt), _f32(gout)
+    B, C, H, W = img.shape
+    gimg, gflow, gfilt = np.zeros_like(img), np.zeros_like(flow), np.zeros_like(filt)
+    _check(lib().vfi_oracle_filterinterp_ori_bwd(_p(img), _p(flow), _p(filt), _p(gout), _p(gimg), _p(gflow),
+                                                 _p(gfilt), B, C, H, W, filt.shape[1], int(fmad)),
+           "filterinterp_ori_bwd")
+    return gimg, gflow, gfilt
+
+
+def filterinterp_defor_fwd(variant, img, flow, filt, off, fmad=0):
+    """variant 0: 4-input forward; 1: deforconv; 2: nofilterwithdeforconv (filt ignored)."""
+    img, flow, off = _f32(img), _f32(flow), _f32(off)
+    B, C, H, W = img.shape
+    fs = int(np.sqrt(np.float32(off.shape[1] // 2)))
+    if variant != 2:
+        filt = _f32(filt)
+        fs = int(np.sqrt(np.float32(filt.shape[1])))
+        fp = _p(filt)
+    else:
+        fp = None
+    out = np.zeros_like(img)
+    _check(lib().vfi_oracle_filterinterp_defor_fwd(int(variant), _p(img), _p(flow), fp, _p(off), _p(out),
+                                                   B, C, H, W, fs, int(fmad)), "filterinterp_defor_fwd")
+    return out
+
+
+def flowproj_fwd(flow, fillhole=1):
+    flow = _f32(flow)
+    B, _, H, W = flow.shape
+    count = np.zeros((B, 1, H, W), np.float32)
+    out = np.zeros_like(flow)
+    _check(lib().vfi_oracle_flowproj_fwd(_p(flow), _p(count), _p(out), B, H, W, int(fillhole)), "flowproj_fwd")
+    return out, count
+
+
+def flowproj_bwd(flow, count, gout):
+    flow, count, gout = _f32(flow), _f32(count), _f32(gout)
+    B, _, H, W = flow.shape
+    gflow = np.zeros_like(flow)
+    _check(lib().vfi_oracle_flowproj_bwd(_p(flow), _p(count), _p(gout), _p(gflow), B, H, W), "flowproj_bwd")
+    return gflow
+
+
+def depthflowproj_fwd(flow, depth, fillhole=1):
+    flow, depth = _f32(flow), _f32(depth)
+    B, _, H, W = flow.shape
+    count = np.zeros((B, 1, H, W), np.float32)
+    out = np.zeros_like(flow)
+    _check(lib().vfi_oracle_depthflowproj_fwd(_p(flow), _p(depth), _p(count), _p(out), B, H, W, int(fillhole), 0),
+           "depthflowproj_fwd")
+    return out, count
+
+
+def depthflowproj_bwd(flow, depth, count, out, gout):
+    flow, depth, count, out, gout = _f32(flow), _f32(depth), _f32(count), _f32(out), _f32(gout)
+    B, _, H, W = flow.shape
+    gflow, gdepth = np.zeros_like(flow), np.zeros_like(depth)
+    _check(lib().vfi_oracle_depthflowproj_bwd(_p(flow), _p(depth), _p(count), _p(out), _p(gout), _p(gflow),
+                                              _p(gdepth), B, H, W), "depthflowproj_bwd")
+    return gflow, gdepth
+
+
+def interp_fwd(img, flow, fmad=0):
+    img, flow = _f32(img), _f32(flow)
+    B, C, H, W = img.shape
+    out = np.zeros_like(img)
+    _check(lib().vfi_oracle_interp_fwd(_p(img), _p(flow), _p(out), B, C, H, W, int(fmad)), "interp_fwd")
+    return out
+
+
+def interp_bwd(img, flow, gout, fmad=0):
+    img, flow, gout = _f32(img), _f32(flow), _f32(gout)
+    B, C, H, W = img.shape
+    gimg, gflow = np.zeros_like(img), np.zeros_like(flow)
+    _check(lib().vfi_oracle_interp_bwd(_p(img), _p(flow), _p(gout), _p(gimg), _p(gflow), B, C, H, W, int(fmad)),
+           "interp_bwd")
+    return gimg, gflow
+
+
+def sepconv_fwd(img, v, h, fmad=0):
+    img, v, h = _f32(img), _f32(v), _f32(h)
+    B, C, H, W = img.shape
+    fs = v.shape[1]
+    out = np.zeros((B, C, H - fs + 1, W - fs + 1), np.float32)
+    _check(lib().vfi_oracle_sepconv_fwd(_p(img), _p(v), _p(h), _p(out), B, C, H, W, fs, int(fmad)), "sepconv_fwd")
+    return out
+
+
+def sepconv_bwd(img, v, h, gout):
+    img, v, h, gout = _f32(img), _f32(v), _f32(h), _f32(gout)
+    B, C, H, W = img.shape
+    fs = v.shape[1]
+    gimg, gv, gh = np.zeros_like(img), np.zeros_like(v), np.zeros_like(h)
+    _check(lib().vfi_oracle_sepconv_bwd(_p(img), _p(v), _p(h), _p(gout), _p(gimg), _p(gv), _p(gh), B, C, H, W, fs),
+           "sepconv_bwd")
+    return gimg, gv, gh
+
+
+def sepconvflow_fwd(v, h, H, W, fmad=0):
+    v, h = _f32(v), _f32(h)
+    B, fs = v.shape[0], v.shape[1]
+    out = np.zeros((B, 2, H - fs + 1, W - fs + 1), np.float32)
+    _check(lib().vfi_oracle_sepconvflow_fwd(_p(v), _p(h), _p(out), B, H, W, fs, int(fmad)), "sepconvflow_fwd")
+    return out
+
+
+def sepconvflow_bwd(v, h, gflow, H, W, fmad=0):
+    v, h, gflow = _f32(v), _f32(h), _f32(gflow)
+    B, fs = v.shape[0], v.shape[1]
+    gv, gh = np.zeros_like(v), np.zeros_like(h)
+    _check(lib().vfi_oracle_sepconvflow_bwd(_p(v), _p(h), _p(gflow), _p(gv), _p(gh), B, H, W, fs, int(fmad)),
+           "sepconvflow_bwd")
+    return gv, gh
+
+
+def correlation_out_dims(H, W, pad, k, md, s1, s2):
+    oc, oh, ow = _I(), _I(), _I()
+    _check(lib().vfi_oracle_correlation_out_dims(H, W, pad, k, md, s1, s2, ctypes.byref(oc), ctypes.byref(oh),
+                                                 ctypes.byref(ow)), "correlation_out_dims")
+    return oc.value, oh.value, ow.value
+
+
+def correlation_fwd(f1, f2, pad=4, k=1, md=4, s1=1, s2=1, order=0, fmad=0):
+    f1, f2 = _f32(f1), _f32(f2)
+    B, C, H, W = f1.shape
+    oc, oh, ow = correlation_out_dims(H, W, pad, k, md, s1, s2)
+    out = np.zeros((B, oc, oh, ow), np.float32)
+    _check(lib().vfi_oracle_correlation_fwd(_p(f1), _p(f2), _p(out), B, C, H, W, pad, k, md, s1, s2, int(order),
+                                            int(fmad)), "correlation_fwd")
+    return out
+
+
+def correlation_bwd(f1, f2, gout, pad=4, k=1, md=4, s1=1, s2=1):
+    f1, f2, gout = _f32(f1), _f32(f2), _f32(gout)
+    B, C, H, W = f1.shape
+    g1, g2 = np.zeros_like(f1), np.zeros_like(f2)
+    _check(lib().vfi_oracle_correlation_bwd(_p(f1), _p(f2), _p(gout), _p(g1), _p(g2), B, C, H, W, pad, k, md, s1,
+                                            s2), "correlation_bwd")
+    return g1, g2

@@ -1,0 +1,334 @@
+"""ctypes caller of libvfi_hip.so (include/vfi_hip.h) for torch GPU tensors.
+
+Each function is the ctypes twin of one reference binding: it applies the
+binding's own shape/stride checks (returning 1 silently on a mismatch, like
+`filterinterpolation_cuda.cc:543-583`), then passes raw device pointers, sizes,
+element strides and torch's current HIP stream to the C ABI.  No arithmetic
+happens on this side.  torch is used for memory and streams only.
+"""
+import ctypes
+import math
+
+import torch  # must be imported before libvfi_hip.so so both bind the same libamdhip64.so.7
+
+from . import LIB_PATH
+
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+
+
+class Strides(ctypes.Structure):
+    _fields_ = [("b", ctypes.c_int64), ("c", ctypes.c_int64), ("h", ctypes.c_int64)]
+
+
+VFI_OK, VFI_ERR_SHAPE, VFI_ERR_LAUNCH = 0, 1, -2
+DEFOR_OFFSET, DEFOR_REGION, DEFOR_NOFILTER = 0, 1, 2
+
+# name -> argtypes, exactly the declarations of include/vfi_hip.h
+SIGNATURES = {
+    "vfi_filterinterp_forward_ori": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_backward_ori": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_forward_defor": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
+                                       Strides, _p],
+    "vfi_flowprojection_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
+    "vfi_flowprojection_backward": [_p, _p, _p, _p, _i, _i, _i, Strides, Strides, _p],
+    "vfi_depthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_depthflowprojection_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_interpolation_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
+    "vfi_interpolation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
+    "vfi_separableconv_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, Strides, _p],
+    "vfi_separableconv_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
+                                   Strides, _p],
+    "vfi_separableconvflow_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_separableconvflow_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_correlation_output_dims": [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i),
+                                    ctypes.POINTER(_i)],
+    "vfi_correlation_forward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "vfi_correlation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+}
+# internal entry points used by the bench / tests to time one code path in isolation
+INTERNAL_SIGNATURES = {
+    "vfi_filterinterp_forward_ori_direct": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libvfi_hip.so; raises OSError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        l = ctypes.CDLL(LIB_PATH)
+        l.vfi_version.restype = ctypes.c_char_p
+        l.vfi_version.argtypes = []
+        for table in (SIGNATURES, INTERNAL_SIGNATURES):
+            for name, argtypes in table.items():
+                fn = getattr(l, name)
+                fn.restype = _i
+                fn.argtypes = argtypes
+        _lib = l
+    return _lib
+
+
+def version():
+    return lib().vfi_version().decode()
+
+
+def _st(t):
+    return Strides(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    if not t.is_cuda:
+        raise RuntimeError("vfidkr_amd.cabi: tensors must live on the GPU (there is no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError("vfidkr_amd.cabi: tensors must be float32")
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _finish(err):
+    if err == VFI_ERR_LAUNCH:
+        raise RuntimeError("CUDA call failed")      # the reference's AT_ERROR text
+    return err
+
+
+# ---------------------------------------------------------------- filterinterpolation_cuda
+
+def _fi_checks(input1, input2, input3, out_like):
+    b, c, h, w = input1.shape
+    if input2.size(0) != b or input2.size(1) != 2 or input2.size(2) != h or input2.size(3) != w:
+        return None
+    if input1.stride(3) != 1 or input2.stride(3) != 1 or input3.stride(3) != 1:
+        return None
+    if out_like is not None and (input1.stride(0) != out_like.stride(0) or input1.stride(1) != out_like.stride(1)):
+        return None
+    return b, c, h, w
+
+
+def filterinterp_forward_ori(input1, input2, input3, output, direct=False):
+    dims = _fi_checks(input1, input2, input3, output)
+    if dims is None:
+        return 1
+    b, c, h, w = dims
+    with torch.cuda.device(input1.device):
+        fn = lib().vfi_filterinterp_forward_ori_direct if direct else lib().vfi_filterinterp_forward_ori
+        return _finish(fn(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c, h, w, input3.size(1),
+                          _st(input1), _st(input2), _st(input3), _stream(input1)))
+
+
+def filterinterp_backward_ori(input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3):
+    dims = _fi_checks(input1, input2, input3, gradinput1)
+    if dims is None:
+        return 1
+    if input2.stride(0) != gradinput2.stride(0) or input2.stride(1) != gradinput2.stride(1):
+        return 1
+    if input3.stride(1) != gradinput3.stride(1):
+        return 1
+    b, c, h, w = dims
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_filterinterp_backward_ori(
+            _ptr(input1), _ptr(input2), _ptr(input3), _ptr(gradoutput), _ptr(gradinput1), _ptr(gradinput2),
+            _ptr(gradinput3), b, c, h, w, input3.size(1), _st(input1), _st(input2), _st(input3), _stream(input1)))
+
+
+def filterinterp_forward_defor(variant, input1, input2, input3, input4, output):
+    """variant: DEFOR_OFFSET (4-input forward), DEFOR_REGION (deforconv), DEFOR_NOFILTER (input4 = None)."""
+    dims = _fi_checks(input1, input2, input3, output if variant == DEFOR_NOFILTER else None)
+    if dims is None:
+        return 1
+    b, c, h, w = dims
+    if variant == DEFOR_NOFILTER:
+        fs = int(math.sqrt(input3.size(1) // 2))
+        p4, s4 = ctypes.c_void_p(0), _st(input3)
+    else:
+        if input4.stride(3) != 1:
+            return 1
+        fs = int(math.sqrt(input3.size(1)))
+        p4, s4 = _ptr(input4), _st(input4)
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_filterinterp_forward_defor(
+            variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(output), b, c, h, w, fs, _st(input1),
+            _st(input2), _st(input3), s4, _stream(input1)))
+
+
+# ---------------------------------------------------------------- flowprojection_cuda / depthflowprojection_cuda
+
+def flowprojection_forward(input1, count, output, fillhole):
+    if input1.size(1) != 2:
+        return 1
+    if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
+        return 1
+    b, _, h, w = input1.shape
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_flowprojection_forward(_ptr(input1), _ptr(count), _ptr(output), b, h, w,
+                                                        int(fillhole), _st(input1), _st(count), _stream(input1)))
+
+
+def flowprojection_backward(input1, count, gradoutput, gradinput1):
+    b, _, h, w = input1.shape
+    if input1.size(1) != 2 or tuple(count.shape) != (b, 1, h, w):
+        return 1
+    if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
+        return 1
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_flowprojection_backward(_ptr(input1), _ptr(count), _ptr(gradoutput),
+                                                         _ptr(gradinput1), b, h, w, _st(input1), _st(count),
+                                                         _stream(input1)))
+
+
+def depthflowprojection_forward(input1, input2, count, output, fillhole):
+    if input1.size(1) != 2 or input2.size(1) != 1:
+        return 1
+    if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
+        return 1
+    b, _, h, w = input1.shape
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_depthflowprojection_forward(
+            _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), b, h, w, int(fillhole), _st(input1), _st(input2),
+            _st(count), _stream(input1)))
+
+
+def depthflowprojection_backward(input1, input2, count, output, gradoutput, gradinput1, gradinput2):
+    b, _, h, w = input1.shape
+    if input1.size(1) != 2 or input2.size(1) != 1 or tuple(count.shape) != (b, 1, h, w):
+        return 1
+    if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
+        return 1
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_depthflowprojection_backward(
+            _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), _ptr(gradoutput), _ptr(gradinput1),
+            _ptr(gradinput2), b, h, w, _st(input1), _st(input2), _st(count), _stream(input1)))
+
+
+# ---------------------------------------------------------------- interpolation_cuda / interpolationch_cuda
+
+def interpolation_forward(input1, input2, output, require_c3=False):
+    b, c, h, w = input1.shape
+    if require_c3 and c != 3:
+        return 1
+    if tuple(input2.shape) != (b, 2, h, w):
+        return 1
+    if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
+        return 1
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_interpolation_forward(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w,
+                                                       _st(input1), _st(input2), _stream(input1)))
+
+
+def interpolation_backward(input1, input2, gradoutput, gradinput1, gradinput2, require_c3=False):
+    b, c, h, w = input1.shape
+    if require_c3 and c != 3:
+        return 1
+    if tuple(input2.shape) != (b, 2, h, w):
+        return 1
+    if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
+        return 1
+    if input2.stride(0) != gradinput2.stride(0) or input2.stride(1) != gradinput2.stride(1):
+        return 1
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_interpolation_backward(_ptr(input1), _ptr(input2), _ptr(gradoutput),
+                                                        _ptr(gradinput1), _ptr(gradinput2), b, c, h, w, _st(input1),
+                                                        _st(input2), _stream(input1)))
+
+
+# ---------------------------------------------------------------- separableconv_cuda / separableconvflow_cuda
+
+def _sep_checks(input1, input2, input3):
+    b, c, h, w = input1.shape
+    fs = input2.size(1)
+    if c != 3 or input2.size(0) != b or input2.size(1) != input3.size(1):
+        return None
+    if input2.size(2) != h - fs + 1 or input2.size(3) != w - fs + 1:
+        return None
+    if input1.stride(3) != 1 or input2.stride(3) != 1 or input3.stride(3) != 1:
+        return None
+    if input2.stride(0) != input3.stride(0) or input2.stride(1) != input3.stride(1):
+        return None
+    return b, c, h, w, fs
+
+
+def separableconv_forward(input1, input2, input3, output):
+    dims = _sep_checks(input1, input2, input3)
+    if dims is None or output.stride(3) != 1:
+        return 1
+    b, c, h, w, fs = dims
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_separableconv_forward(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c,
+                                                       h, w, fs, _st(input1), _st(input2), _st(input3), _st(output),
+                                                       _stream(input1)))
+
+
+def separableconv_backward(input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3):
+    dims = _sep_checks(input1, input2, input3)
+    if dims is None or gradoutput.stride(3) != 1:
+        return 1
+    b, c, h, w, fs = dims
+    with torch.cuda.device(input1.device):
+        return _finish(lib().vfi_separableconv_backward(
+            _ptr(input1), _ptr(input2), _ptr(input3), _ptr(gradoutput), _ptr(gradinput1), _ptr(gradinput2),
+            _ptr(gradinput3), b, c, h, w, fs, _st(input1), _st(input2), _st(input3), _st(gradoutput),
+            _stream(input1)))
+
+
+def separableconvflow_forward(input1, input2, input3, flow_output):
+    dims = _sep_checks(input1, input2, input3)
+    if dims is None or flow_output.stride(3) != 1:
+        return 1
+    b, c, h, w, fs = dims
+    with torch.cuda.device(input2.device):
+        return _finish(lib().vfi_separableconvflow_forward(_ptr(input2), _ptr(input3), _ptr(flow_output), b, h, w,
+                                                           fs, _st(input2), _st(input3), _st(flow_output),
+                                                           _stream(input2)))
+
+
+def separableconvflow_backward(input1, input2, input3, gradflow_output, gradinput2, gradinput3):
+    dims = _sep_checks(input1, input2, input3)
+    if dims is None or gradflow_output.stride(3) != 1:
+        return 1
+    b, c, h, w, fs = dims
+    with torch.cuda.device(input2.device):
+        return _finish(lib().vfi_separableconvflow_backward(
+            _ptr(input2), _ptr(input3), _ptr(gradflow_output), _ptr(gradinput2), _ptr(gradinput3), b, h, w, fs,
+            _st(input2), _st(input3), _st(gradflow_output), _stream(input2)))
+
+
+# ---------------------------------------------------------------- correlation_cuda
+
+def correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2):
+    oc, oh, ow = _i(), _i(), _i()
+    err = lib().vfi_correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                            ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow))
+    if err != 0:
+        raise RuntimeError("CUDA call failed")
+    return oc.value, oh.value, ow.value
+
+
+def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """Allocates and returns the output, as the reference binding resizes its `output` argument."""
+    input1, input2 = input1.contiguous(), input2.contiguous()
+    b, c, h, w = input1.shape
+    oc, oh, ow = correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2)
+    output = torch.empty((b, oc, oh, ow), dtype=torch.float32, device=input1.device)
+    with torch.cuda.device(input1.device):
+        err = lib().vfi_correlation_forward(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w, pad_size,
+                                            kernel_size, max_displacement, stride1, stride2, _stream(input1))
+    if err != 0:
+        raise RuntimeError("CUDA call failed")
+    return output
+
+
+def correlation_backward(input1, input2, gradoutput, pad_size, kernel_size, max_displacement, stride1, stride2):
+    input1, input2, gradoutput = input1.contiguous(), input2.contiguous(), gradoutput.contiguous()
+    b, c, h, w = input1.shape
+    g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
+    with torch.cuda.device(input1.device):
+        err = lib().vfi_correlation_backward(_ptr(input1), _ptr(input2), _ptr(gradoutput), _ptr(g1), _ptr(g2), b, c,
+                                             h, w, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                             _stream(input1))
+    if err != 0:
+        raise RuntimeError("CUDA call failed")
+    return g1, g2

@@ -1,0 +1,351 @@
+// filterinterp.hip -- adaptive-warping layer (FilterInterpolation) for gfx950.
+//
+// Semantics: filterinterpolation_cuda_kernel.cu:2692-2823 (_ori forward),
+// :2827-3125 (_ori backward), :29-426 / :1353-1496 / :2070-2191 (deformable
+// forwards) of the reference; entry points replace filterinterpolation_cuda.cc.
+//
+// This file holds the direct-gather kernels: one thread per output pixel, a
+// wave covers 64 consecutive x so flow / filter / output planes move as full
+// 256-B rows; flow, the blend weights and (fs == 4) all 16 filter taps live in
+// registers across the channel loop (the reference re-fetches them per channel).
+// The LDS-staged forward for fs == 4 lives in filterinterp_lds.hip and falls
+// back to the kernel here when a tile's tap window does not fit its LDS budget.
+#include "filterinterp_dev.h"
+
+namespace vfi {
+
+// ------------------------------------------------------------------ forward, _ori
+
+// quadrant sums for a runtime filter size, rows outer / columns inner per quadrant
+__device__ __forceinline__ void quadrants_generic(const float* __restrict__ plane, const float* __restrict__ fpx,
+                                                  int64_t fcs, int hs, int h, int w, int fs,
+                                                  int L, int T, int ix, int iy, float q[4]) {
+    const int R = L + fs, Bm = T + fs;
+    float TL = 0.0f, TR = 0.0f, BL = 0.0f, BR = 0.0f;
+    for (int j = T; j <= iy; ++j) {
+        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
+        for (int i = L; i <= ix; ++i)
+            TL = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], TL);
+    }
+    for (int j = T; j <= iy; ++j) {
+        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
+        for (int i = ix + 1; i < R; ++i)
+            TR = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], TR);
+    }
+    for (int j = iy + 1; j < Bm; ++j) {
+        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
+        for (int i = L; i <= ix; ++i)
+            BL = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], BL);
+    }
+    for (int j = iy + 1; j < Bm; ++j) {
+        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
+        for (int i = ix + 1; i < R; ++i)
+            BR = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], BR);
+    }
+    q[0] = TL; q[1] = TR; q[2] = BL; q[3] = BR;
+}
+
+template <bool FS4>
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    float* __restrict__ out, int channel, int h, int w, int fs,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    const float* img = in1 + (int64_t)b * s1.b;
+    float* dst = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    if (!fi_valid(fx, fy, x2, y2, w, h)) {
+        // copy-through (:2814-2818)
+        const float* src = img + (int64_t)y * s1.h + x;
+        for (int c = 0; c < channel; ++c) dst[(int64_t)c * s1.c] = src[(int64_t)c * s1.c];
+        return;
+    }
+    const int ix = (int)x2, iy = (int)y2;
+    const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    if constexpr (FS4) {
+        // fs == 4: every quadrant is 2x2; taps, clamped rows and columns hoisted out of the channel loop
+        float f[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = fpx[(int64_t)k * s3.c];
+        fi4_channels_direct(img, dst, 0, channel, s1.c, (int)s1.h, h, w, L, T, f, alpha, beta);
+    } else {
+        for (int c = 0; c < channel; ++c) {
+            float q[4];
+            quadrants_generic(img + (int64_t)c * s1.c, fpx, s3.c, (int)s1.h, h, w, fs, L, T, ix, iy, q);
+            dst[(int64_t)c * s1.c] = blend4(alpha, beta, q[0], q[1], q[2], q[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward, _ori
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    const float* __restrict__ gout, float* g1, float* g2, float* g3,
+    int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    if (!fi_valid(fx, fy, x2, y2, w, h)) return;           // no gradient (:2863-2864)
+    const int ix = (int)x2, iy = (int)y2;
+    const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    const int R = L + fs, Bm = T + fs;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    const float* img = in1 + (int64_t)b * s1.b;
+    float* gimg = g1 + (int64_t)b * s1.b;
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    float* gfpx = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    float gx = 0.0f, gy = 0.0f;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = img + (int64_t)c * s1.c;
+        float* gp = gimg + (int64_t)c * s1.c;
+        const float g = gpx[(int64_t)c * s1.c];
+        const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
+                              g * (1.0f - alpha) * beta,          g * alpha * beta };
+        float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int quad = 0; quad < 4; ++quad) {
+            const int j0 = (quad < 2) ? T : iy + 1, j1 = (quad < 2) ? iy : Bm - 1;
+            const int i0 = (quad & 1) ? ix + 1 : L, i1 = (quad & 1) ? R - 1 : ix;
+            float acc = 0.0f;
+            for (int j = j0; j <= j1; ++j) {
+                const int64_t ro = (int64_t)clampi(j, 0, h - 1) * s1.h;
+                for (int i = i0; i <= i1; ++i) {
+                    const int64_t o = ro + clampi(i, 0, w - 1);
+                    const int64_t k = (int64_t)((j - T) * fs + (i - L)) * s3.c;
+                    const float pv = p[o], fv = fpx[k];
+                    // image gradient: other pixels hit the same cell -> atomic.  The filter
+                    // gradient cell belongs to this thread alone (index is this pixel's own),
+                    // so a plain read-modify-write is equivalent to the reference's atomicAdd.
+                    atomicAdd(&gp[o], qg[quad] * fv);
+                    gfpx[k] += qg[quad] * pv;
+                    acc = fmaf(pv, fv, acc);
+                }
+            }
+            q[quad] = acc;
+        }
+        {   // flow gradient by quadrant differences (:2965-3102)
+            const float gamma = 1.0f - beta;
+            float temp = gamma * (q[1] - q[0]);
+            temp = fmaf(1.0f - gamma, q[3] - q[2], temp);
+            gx = fmaf(g, temp, gx);
+        }
+        {
+            const float gamma = 1.0f - alpha;
+            float temp = gamma * (q[2] - q[0]);
+            temp = fmaf(1.0f - gamma, q[3] - q[1], temp);
+            gy = fmaf(g, temp, gy);
+        }
+    }
+    float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    gf[0] = gx;
+    gf[s2.c] = gy;
+}
+
+// ------------------------------------------------------------------ forward, deformable variants
+
+// bilinear sample at (clamped tap + learned offset) (:98-111); the four corner
+// indices are clamped to the image (the reference leaves them unclamped: UB there)
+__device__ __forceinline__ float defor_tap(const float* __restrict__ p, int hs, int h, int w, float fracY, float fracX) {
+    const int Top = (int)fracY, Left = (int)fracX;
+    const float phiY = fracY - (float)Top;
+    const float phiX = fracX - (float)Left;
+    const float PTL = (1.0f - phiX) * (1.0f - phiY);
+    const float PTR = phiX * (1.0f - phiY);
+    const float PBL = (1.0f - phiX) * phiY;
+    const float PBR = phiY * phiX;
+    const int64_t t = (int64_t)clampi(Top, 0, h - 1) * hs, bo = (int64_t)clampi(Top + 1, 0, h - 1) * hs;
+    const int l = clampi(Left, 0, w - 1), r = clampi(Left + 1, 0, w - 1);
+    float s = PTL * p[t + l];
+    s = fmaf(PTR, p[t + r], s);
+    s = fmaf(PBL, p[bo + l], s);
+    s = fmaf(PBR, p[bo + r], s);
+    return s;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_defor(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    const float* __restrict__ in4, float* __restrict__ out, int channel, int h, int w, int fs,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    const float* img = in1 + (int64_t)b * s1.b;
+    float* dst = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    if (!fi_valid(fx, fy, x2, y2, w, h)) {
+        const float* src = img + (int64_t)y * s1.h + x;
+        for (int c = 0; c < channel; ++c) dst[(int64_t)c * s1.c] = src[(int64_t)c * s1.c];
+        return;
+    }
+    const int fs2 = fs * fs;
+    const int ix = (int)x2, iy = (int)y2;
+    const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    const int R = L + fs, Bm = T + fs;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    // VARIANT 2: the third input IS the offset field, there are no filter weights
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    const float* opx = (VARIANT == VFI_DEFOR_NOFILTER) ? fpx : in4 + (int64_t)b * s4.b + (int64_t)y * s4.h + x;
+    const int64_t ocs = (VARIANT == VFI_DEFOR_NOFILTER) ? s3.c : s4.c;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = img + (int64_t)c * s1.c;
+        float TL = 0.0f, TR = 0.0f, BL = 0.0f, BR = 0.0f;
+        if constexpr (VARIANT == VFI_DEFOR_OFFSET) {
+            for (int quad = 0; quad < 4; ++quad) {
+                const int j0 = (quad < 2) ? T : iy + 1, j1 = (quad < 2) ? iy : Bm - 1;
+                const int i0 = (quad & 1) ? ix + 1 : L, i1 = (quad & 1) ? R - 1 : ix;
+                float acc = 0.0f;
+                for (int j = j0; j <= j1; ++j) {
+                    const int cj = clampi(j, 0, h - 1);
+                    for (int i = i0; i <= i1; ++i) {
+                        const int ci = clampi(i, 0, w - 1);
+                        const int k = (j - T) * fs + (i - L);
+                        const float fracY = (float)cj + opx[(int64_t)k * ocs];
+                        const float fracX = (float)ci + opx[(int64_t)(fs2 + k) * ocs];
+                        acc = fmaf(defor_tap(p, (int)s1.h, h, w, fracY, fracX), fpx[(int64_t)k * s3.c], acc);
+                    }
+                }
+                if (quad == 0) TL = acc; else if (quad == 1) TR = acc; else if (quad == 2) BL = acc; else BR = acc;
+            }
+        } else {
+            for (int j = T; j < Bm; ++j) {
+                const int cj = clampi(j, 0, h - 1);
+                for (int i = L; i < R; ++i) {
+                    const int ci = clampi(i, 0, w - 1);
+                    const int k = (j - T) * fs + (i - L);
+                    const float fracY = (float)cj + opx[(int64_t)k * ocs];
+                    const float fracX = (float)ci + opx[(int64_t)(fs2 + k) * ocs];
+                    const float v = defor_tap(p, (int)s1.h, h, w, fracY, fracX);
+                    if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
+                        if (fracX <= x2 && fracY <= y2) TL = TL + v;
+                        if (fracX >  x2 && fracY <= y2) TR = TR + v;
+                        if (fracX <= x2 && fracY >  y2) BL = BL + v;
+                        if (fracX >  x2 && fracY >  y2) BR = BR + v;
+                    } else {
+                        const float wgt = fpx[(int64_t)k * s3.c];
+                        if (fracX <= x2 && fracY <= y2) TL = fmaf(v, wgt, TL);
+                        if (fracX >  x2 && fracY <= y2) TR = fmaf(v, wgt, TR);
+                        if (fracX <= x2 && fracY >  y2) BL = fmaf(v, wgt, BL);
+                        if (fracX >  x2 && fracY >  y2) BR = fmaf(v, wgt, BR);
+                    }
+                }
+            }
+        }
+        dst[(int64_t)c * s1.c] = blend4(alpha, beta, TL, TR, BL, BR);
+    }
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+// defined in filterinterp_lds.hip; returns VFI_OK / VFI_ERR_LAUNCH, or -1 when it declines the shape
+extern "C" int vfi_filterinterp_forward_ori_lds(const float*, const float*, const float*, float*,
+                                                 int, int, int, int, vfi_strides, vfi_strides, vfi_strides,
+                                                 vfi_stream_t);
+
+static int fi_filter_size(int filter_channels) { return (int)sqrtf((float)filter_channels); }
+
+extern "C" int vfi_filterinterp_forward_ori_direct(const float* input1, const float* input2, const float* input3,
+                                                    float* output, int batch, int channel, int h, int w,
+                                                    int filter_channels, vfi_strides s1, vfi_strides s2,
+                                                    vfi_strides s3, vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    const int fs = fi_filter_size(filter_channels);
+    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (fs == 4)
+        hipLaunchKernelGGL(fi_forward_ori_direct<true>, grid, block, 0, st, input1, input2, input3, output,
+                           channel, h, w, fs, s1, s2, s3);
+    else
+        hipLaunchKernelGGL(fi_forward_ori_direct<false>, grid, block, 0, st, input1, input2, input3, output,
+                           channel, h, w, fs, s1, s2, s3);
+    return launch_status();
+}
+
+extern "C" int vfi_filterinterp_forward_ori(const float* input1, const float* input2, const float* input3,
+                                             float* output, int batch, int channel, int h, int w,
+                                             int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                             vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    if (fi_filter_size(filter_channels) == 4) {
+        const int r = vfi_filterinterp_forward_ori_lds(input1, input2, input3, output, batch, channel, h, w,
+                                                       s1, s2, s3, stream);
+        if (r != -1) return r;
+    }
+    return vfi_filterinterp_forward_ori_direct(input1, input2, input3, output, batch, channel, h, w,
+                                               filter_channels, s1, s2, s3, stream);
+}
+
+extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* input2, const float* input3,
+                                              const float* gradoutput, float* gradinput1, float* gradinput2,
+                                              float* gradinput3, int batch, int channel, int h, int w,
+                                              int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                              vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3)
+        return VFI_ERR_SHAPE;
+    const int fs = fi_filter_size(filter_channels);
+    hipLaunchKernelGGL(fi_backward_ori, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3,
+                       channel, h, w, fs, s1, s2, s3);
+    return launch_status();
+}
+
+extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, const float* input2,
+                                               const float* input3, const float* input4, float* output,
+                                               int batch, int channel, int h, int w, int filter_size,
+                                               vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                               vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_size <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    if (variant != VFI_DEFOR_NOFILTER && !input4) return VFI_ERR_SHAPE;
+    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+    case VFI_DEFOR_OFFSET:
+        // the reference kernel has a body for fs 4 and 6 only; other sizes leave
+        // the caller's (zero-filled) output untouched (:68)
+        if (!(filter_size == 4 || filter_size == 6)) return VFI_OK;
+        hipLaunchKernelGGL(fi_forward_defor<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
+                           output, channel, h, w, filter_size, s1, s2, s3, s4);
+        break;
+    case VFI_DEFOR_REGION:
+        hipLaunchKernelGGL(fi_forward_defor<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
+                           output, channel, h, w, filter_size, s1, s2, s3, s4);
+        break;
+    case VFI_DEFOR_NOFILTER:
+        hipLaunchKernelGGL(fi_forward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3,
+                           input3, output, channel, h, w, filter_size, s1, s2, s3, s3);
+        break;
+    default:
+        return VFI_ERR_SHAPE;
+    }
+    return launch_status();
+}

@@ -1,0 +1,41 @@
+// filterinterp_dev.h -- per-pixel device code shared by the direct and the
+// LDS-staged FilterInterpolation (_ori, fs == 4) forward kernels.
+#pragma once
+#include "vfi_common.h"
+
+namespace vfi {
+
+// One pixel's 4x4 window, fs == 4: every quadrant is 2x2.  v = the 16 image
+// taps (row major), f = the 16 filter taps.  Accumulation order inside each
+// quadrant is rows outer, columns inner (filterinterpolation_cuda_kernel.cu:2749-2787);
+// `acc += a*b` fused as nvcc -fmad=true fuses it.
+__device__ __forceinline__ float fi4_pixel(const float (&v)[16], const float (&f)[16], float alpha, float beta) {
+    float TL = v[0] * f[0];   TL = fmaf(v[1], f[1], TL);   TL = fmaf(v[4], f[4], TL);   TL = fmaf(v[5], f[5], TL);
+    float TR = v[2] * f[2];   TR = fmaf(v[3], f[3], TR);   TR = fmaf(v[6], f[6], TR);   TR = fmaf(v[7], f[7], TR);
+    float BL = v[8] * f[8];   BL = fmaf(v[9], f[9], BL);   BL = fmaf(v[12], f[12], BL); BL = fmaf(v[13], f[13], BL);
+    float BR = v[10] * f[10]; BR = fmaf(v[11], f[11], BR); BR = fmaf(v[14], f[14], BR); BR = fmaf(v[15], f[15], BR);
+    return blend4(alpha, beta, TL, TR, BL, BR);
+}
+
+// channel loop of one valid pixel gathering straight from global memory
+__device__ __forceinline__ void fi4_channels_direct(const float* __restrict__ img, float* __restrict__ dst,
+                                                    int c0, int c1, int64_t cs, int hs, int h, int w,
+                                                    int L, int T, const float (&f)[16], float alpha, float beta) {
+    int ro[4], co[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ro[k] = clampi(T + k, 0, h - 1) * hs;
+        co[k] = clampi(L + k, 0, w - 1);
+    }
+    for (int c = c0; c < c1; ++c) {
+        const float* p = img + (int64_t)c * cs;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[r * 4 + k] = p[ro[r] + co[k]];
+        dst[(int64_t)c * cs] = fi4_pixel(v, f, alpha, beta);
+    }
+}
+
+}  // namespace vfi

@@ -1,0 +1,54 @@
+// vfi_common.h -- shared device/host helpers for the gfx950 kernels of libvfi_hip.so.
+//
+// Numerics contract (DESIGN.md "numerics"): the library is compiled with
+// -ffp-contract=off; every fused multiply-add is written explicitly with
+// fmaf() at the positions where nvcc's default -fmad=true would fuse the
+// reference's `acc += a*b` statements.  The CPU oracle's fmad=1 mode performs
+// the same operations in the same order, so deterministic ops compare bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vfi_hip.h"
+
+#define VFI_WAVE 64
+
+// Pixel tile of the one-thread-per-pixel kernels: one wave = one 64-pixel row
+// segment (256-B coalesced rows of every plane), four rows per workgroup.
+#define VFI_TX 64
+#define VFI_TY 4
+
+namespace vfi {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// (1-a)(1-b)*TL + a(1-b)*TR + (1-a)b*BL + ab*BR, left to right, adds fused
+// (filterinterpolation_cuda_kernel.cu:2789-2793; interpolation_cuda_kernel.cu:86-87)
+__device__ __forceinline__ float blend4(float a, float b, float TL, float TR, float BL, float BR) {
+    const float w00 = (1.0f - a) * (1.0f - b);
+    const float w10 = a * (1.0f - b);
+    const float w01 = (1.0f - a) * b;
+    const float w11 = a * b;
+    float t = w00 * TL;
+    t = fmaf(w10, TR, t);
+    t = fmaf(w01, BL, t);
+    t = fmaf(w11, BR, t);
+    return t;
+}
+
+// validity test of the adaptive-warping layer (filterinterpolation_cuda_kernel.cu:2735-2736)
+__device__ __forceinline__ bool fi_valid(float fx, float fy, float x2, float y2, int w, int h) {
+    return x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1) &&
+           fabsf(fx) < (float)w / 2.0f && fabsf(fy) < (float)h / 2.0f;
+}
+
+inline dim3 pixel_grid(int w, int h, int batch) {
+    return dim3((unsigned)((w + VFI_TX - 1) / VFI_TX), (unsigned)((h + VFI_TY - 1) / VFI_TY), (unsigned)batch);
+}
+
+inline int launch_status() {
+    return hipGetLastError() == hipSuccess ? VFI_OK : VFI_ERR_LAUNCH;
+}
+
+}  // namespace vfi

@@ -1,0 +1,283 @@
+// warp_sepconv.hip -- Interpolation / InterpolationCh (bilinear backward warp),
+// SeparableConv (local separable convolution) and SeparableConvFlow (kernel
+// centre of mass -> flow) for gfx950.
+//
+// Semantics: interpolation_cuda_kernel.cu:29-202, separableconv_cuda_kernel.cu:29-135,
+// separableconvflow_cuda_kernel.cu:29-173 of the reference; entry points replace
+// interpolation_cuda.cc, interpolationch_cuda.cc, separableconv_cuda.cc and
+// separableconvflow_cuda.cc.  One thread per output pixel, a wave = 64
+// consecutive x (coalesced plane rows), channel loop inside the thread.
+#include "vfi_common.h"
+
+namespace vfi {
+
+// ------------------------------------------------------------------ Interpolation
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_forward(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
+    int channel, int h, int w, vfi_strides s1, vfi_strides s2) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    float* dst = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    if (x2 >= 0.0f && y2 >= 0.0f && x2 < (float)w && y2 < (float)h) {       // strict upper bound (:71)
+        const int L = (int)x2, T = (int)y2;
+        const int R = min(L + 1, w - 1), Bm = min(T + 1, h - 1);
+        const float alpha = x2 - (float)L, beta = y2 - (float)T;
+        const float* img = in1 + (int64_t)b * s1.b;
+        const int64_t oT = (int64_t)T * s1.h, oB = (int64_t)Bm * s1.h;
+        for (int c = 0; c < channel; ++c) {
+            const float* p = img + (int64_t)c * s1.c;
+            dst[(int64_t)c * s1.c] = blend4(alpha, beta, p[oT + L], p[oT + R], p[oB + L], p[oB + R]);
+        }
+    } else {
+        for (int c = 0; c < channel; ++c) dst[(int64_t)c * s1.c] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
+    float* g1, float* g2, int channel, int h, int w, vfi_strides s1, vfi_strides s2) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    if (!(x2 >= 0.0f && y2 >= 0.0f && x2 < (float)w && y2 < (float)h)) return;
+    const int L = (int)x2, T = (int)y2;
+    const int R = min(L + 1, w - 1), Bm = min(T + 1, h - 1);
+    const float alpha = x2 - (float)L, beta = y2 - (float)T;
+    const float* img = in1 + (int64_t)b * s1.b;
+    float* gimg = g1 + (int64_t)b * s1.b;
+    const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    const int64_t oT = (int64_t)T * s1.h, oB = (int64_t)Bm * s1.h;
+    const float gam_y = (float)Bm - y2;         // (:161)
+    const float gam_x = (float)R - x2;          // (:181)
+    float botx = 0.0f, boty = 0.0f;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = img + (int64_t)c * s1.c;
+        float* gp = gimg + (int64_t)c * s1.c;
+        const float g = gpx[(int64_t)c * s1.c];
+        atomicAdd(&gp[oT + L], g * (1.0f - alpha) * (1.0f - beta));     // (:151-158)
+        atomicAdd(&gp[oT + R], g * alpha * (1.0f - beta));
+        atomicAdd(&gp[oB + L], g * (1.0f - alpha) * beta);
+        atomicAdd(&gp[oB + R], g * alpha * beta);
+        const float tl = p[oT + L], tr = p[oT + R], bl = p[oB + L], br = p[oB + R];
+        float temp = gam_y * (tr - tl);
+        temp = fmaf(1.0f - gam_y, br - bl, temp);
+        botx = fmaf(g, temp, botx);
+        temp = gam_x * (bl - tl);
+        temp = fmaf(1.0f - gam_x, br - tr, temp);
+        boty = fmaf(g, temp, boty);
+    }
+    float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    gf[0] = botx;
+    gf[s2.c] = boty;
+}
+
+// ------------------------------------------------------------------ SeparableConv
+
+// out[c] = sum_fy sum_fx (img[c, y+fy, x+fx] * v[fy]) * h[fx]  (:65-77).  Channels are
+// processed CH at a time so v/h are fetched once per tap for all of them; each
+// channel's own accumulation order is the reference's (fy outer, fx inner).
+template <int CH>
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_forward(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    float* __restrict__ out, int channel, int oh, int ow, int fs,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int b = blockIdx.z;
+    const float* vp = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float* hp = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    for (int c0 = 0; c0 < channel; c0 += CH) {
+        float acc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = 0.0f;
+        const float* p = in1 + (int64_t)b * s1.b + (int64_t)c0 * s1.c + (int64_t)y * s1.h + x;
+        for (int fy = 0; fy < fs; ++fy) {
+            const float t2 = vp[(int64_t)fy * s2.c];
+            for (int fx = 0; fx < fs; ++fx) {
+                const float t3 = hp[(int64_t)fx * s3.c];
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (c0 + k < channel)
+                        acc[k] = fmaf(p[(int64_t)k * s1.c + (int64_t)fy * s1.h + fx] * t2, t3, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (c0 + k < channel)
+                out[(int64_t)b * so.b + (int64_t)(c0 + k) * so.c + (int64_t)y * so.h + x] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_backward(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    const float* __restrict__ gout, float* g1, float* g2, float* g3, int channel, int oh, int ow, int fs,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int b = blockIdx.z;
+    const float* vp = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float* hp = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    float* gvp = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    float* ghp = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = in1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
+        float* gp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
+        const float g = gout[(int64_t)b * so.b + (int64_t)c * so.c + (int64_t)y * so.h + x];
+        for (int fy = 0; fy < fs; ++fy) {
+            const float t2 = vp[(int64_t)fy * s2.c];
+            for (int fx = 0; fx < fs; ++fx) {               // (:114-127)
+                const float t3 = hp[(int64_t)fx * s3.c];
+                const float t1 = p[(int64_t)fy * s1.h + fx];
+                atomicAdd(&gp[(int64_t)fy * s1.h + fx], g * t2 * t3);
+                // the v / h gradient cells at (y, x) belong to this thread alone
+                gvp[(int64_t)fy * s2.c] += g * t1 * t3;
+                ghp[(int64_t)fx * s3.c] += g * t1 * t2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ SeparableConvFlow
+
+__device__ __forceinline__ float com_flow(const float* __restrict__ k, int64_t cs, int fs, float* sum_out, float* mom_out) {
+    float mom = 0.0f, sum = 0.0f;
+    for (int f = 0; f < fs; ++f) {
+        const float t = k[(int64_t)f * cs];
+        mom = fmaf((float)f, t, mom);
+        sum += t;
+    }
+    *sum_out = sum;
+    *mom_out = mom;
+    // the reference subtracts ((float)fs - 1.0)/2.0 in double (:75)
+    return (float)((double)(mom / sum) - ((double)(float)fs - 1.0) / 2.0);
+}
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconvflow_forward(
+    const float* __restrict__ in2, const float* __restrict__ in3, float* __restrict__ flow_out,
+    int oh, int ow, int fs, vfi_strides s2, vfi_strides s3, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int b = blockIdx.z;
+    float* o = flow_out + (int64_t)b * so.b + (int64_t)y * so.h + x;
+    float sum, mom;
+    const float fy = com_flow(in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x, s2.c, fs, &sum, &mom);
+    o[so.c] = (fabsf(sum) > 0.0f) ? fy : -2000.0f;
+    const float fx = com_flow(in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x, s3.c, fs, &sum, &mom);
+    o[0] = (fabsf(sum) > 0.0f) ? fx : -2000.0f;
+}
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconvflow_backward(
+    const float* __restrict__ in2, const float* __restrict__ in3, const float* __restrict__ gflow,
+    float* g2, float* g3, int oh, int ow, int fs, vfi_strides s2, vfi_strides s3, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int b = blockIdx.z;
+    const float* gpx = gflow + (int64_t)b * so.b + (int64_t)y * so.h + x;
+    float sum, mom;
+    com_flow(in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x, s2.c, fs, &sum, &mom);
+    if (fabsf(sum) > 0.0f) {                    // plain store (:144)
+        const float g = gpx[so.c];
+        const float offset = mom / (sum * sum);
+        float* gv = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        for (int f = 0; f < fs; ++f) gv[(int64_t)f * s2.c] = g * ((float)f / sum - offset);
+    }
+    com_flow(in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x, s3.c, fs, &sum, &mom);
+    if (fabsf(sum) > 0.0f) {                    // accumulate (:166)
+        const float g = gpx[0];
+        const float offset = mom / (sum * sum);
+        float* gh = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+        for (int f = 0; f < fs; ++f) gh[(int64_t)f * s3.c] = fmaf(g, (float)f / sum - offset, gh[(int64_t)f * s3.c]);
+    }
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" int vfi_interpolation_forward(const float* input1, const float* input2, float* output, int batch,
+                                          int channel, int h, int w, vfi_strides s1, vfi_strides s2,
+                                          vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !output) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(interp_forward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input1, input2, output, channel, h, w, s1, s2);
+    return launch_status();
+}
+
+extern "C" int vfi_interpolation_backward(const float* input1, const float* input2, const float* gradoutput,
+                                           float* gradinput1, float* gradinput2, int batch, int channel, int h, int w,
+                                           vfi_strides s1, vfi_strides s2, vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !gradoutput || !gradinput1 ||
+        !gradinput2)
+        return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(interp_backward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input1, input2, gradoutput, gradinput1, gradinput2, channel, h, w, s1, s2);
+    return launch_status();
+}
+
+extern "C" int vfi_separableconv_forward(const float* input1, const float* input2, const float* input3, float* output,
+                                          int batch, int channel, int h, int w, int filter_size, vfi_strides s1,
+                                          vfi_strides s2, vfi_strides s3, vfi_strides so, vfi_stream_t stream) {
+    const int oh = h - filter_size + 1, ow = w - filter_size + 1;
+    if (batch <= 0 || channel <= 0 || filter_size <= 0 || oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(sepconv_forward<3>, pixel_grid(ow, oh, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input1, input2, input3, output, channel, oh, ow, filter_size, s1, s2, s3, so);
+    return launch_status();
+}
+
+extern "C" int vfi_separableconv_backward(const float* input1, const float* input2, const float* input3,
+                                           const float* gradoutput, float* gradinput1, float* gradinput2,
+                                           float* gradinput3, int batch, int channel, int h, int w, int filter_size,
+                                           vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so,
+                                           vfi_stream_t stream) {
+    const int oh = h - filter_size + 1, ow = w - filter_size + 1;
+    if (batch <= 0 || channel <= 0 || filter_size <= 0 || oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3)
+        return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(sepconv_backward, pixel_grid(ow, oh, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3, channel, oh, ow,
+                       filter_size, s1, s2, s3, so);
+    return launch_status();
+}
+
+extern "C" int vfi_separableconvflow_forward(const float* input2, const float* input3, float* flow_output, int batch,
+                                              int h, int w, int filter_size, vfi_strides s2, vfi_strides s3,
+                                              vfi_strides so, vfi_stream_t stream) {
+    const int oh = h - filter_size + 1, ow = w - filter_size + 1;
+    if (batch <= 0 || filter_size <= 0 || oh <= 0 || ow <= 0 || !input2 || !input3 || !flow_output)
+        return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(sepconvflow_forward, pixel_grid(ow, oh, batch), dim3(VFI_TX, VFI_TY, 1), 0,
+                       (hipStream_t)stream, input2, input3, flow_output, oh, ow, filter_size, s2, s3, so);
+    return launch_status();
+}
+
+extern "C" int vfi_separableconvflow_backward(const float* input2, const float* input3, const float* gradflow_output,
+                                               float* gradinput2, float* gradinput3, int batch, int h, int w,
+                                               int filter_size, vfi_strides s2, vfi_strides s3, vfi_strides so,
+                                               vfi_stream_t stream) {
+    const int oh = h - filter_size + 1, ow = w - filter_size + 1;
+    if (batch <= 0 || filter_size <= 0 || oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
+    if (!input2 || !input3 || !gradflow_output || !gradinput2 || !gradinput3) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(sepconvflow_backward, pixel_grid(ow, oh, batch), dim3(VFI_TX, VFI_TY, 1), 0,
+                       (hipStream_t)stream, input2, input3, gradflow_output, gradinput2, gradinput3, oh, ow,
+                       filter_size, s2, s3, so);
+    return launch_status();
+}

@@ -1,0 +1,90 @@
+"""Mirror of my_package/FilterInterpolation/FilterInterpolationLayer.py:10-92 (reference).
+
+The shipped reference calls the `_ori` kernels (FilterInterpolationLayer.py:35, 73);
+the three deformable-kernel forwards it keeps commented out (:36-38) are exposed
+here as separate Functions so they can be used and tested."""
+import torch
+from torch.autograd import Function
+
+import filterinterpolation_cuda as my_lib
+
+from .._common import require_gpu
+
+
+class FilterInterpolationLayer(Function):
+    @staticmethod
+    def forward(ctx, input1, input2, input3):
+        assert input1.is_contiguous()
+        assert input2.is_contiguous()
+        assert input3.is_contiguous()
+        require_gpu(input1, input2, input3)
+        # the kernel writes every element: no zero fill needed (reference: .zero_(), :34)
+        output = torch.empty_like(input1)
+        err = my_lib.FilterInterpolationLayer_gpu_forward_ori(input1, input2, input3, output)
+        if err != 0:
+            print(err)
+        ctx.save_for_backward(input1, input2, input3)
+        return output
+
+    @staticmethod
+    def backward(ctx, gradoutput):
+        input1, input2, input3 = ctx.saved_tensors
+        gradoutput = gradoutput.contiguous()
+        gradinput1 = torch.zeros_like(input1)
+        gradinput2 = torch.zeros_like(input2)
+        gradinput3 = torch.zeros_like(input3)
+        err = my_lib.FilterInterpolationLayer_gpu_backward_ori(input1, input2, input3, gradoutput, gradinput1,
+                                                              gradinput2, gradinput3)
+        if err != 0:
+            print(err)
+        return gradinput1, gradinput2, gradinput3
+
+
+class _DeformableForward(Function):
+    """Forward-only wrappers of the deformable-kernel variants (no backward kernels yet)."""
+    variant = None
+
+    @classmethod
+    def _run(cls, input1, input2, input3, input4):
+        require_gpu(input1, input2, input3)
+        # 4-input forward leaves the caller's zeros for filter sizes other than 4 and 6
+        output = torch.zeros_like(input1)
+        if cls.variant == "offset":
+            err = my_lib.FilterInterpolationLayer_gpu_forward(input1, input2, input3, input4, output)
+        elif cls.variant == "deforconv":
+            err = my_lib.FilterInterpolationLayer_gpu_forward_deforconv(input1, input2, input3, input4, output)
+        else:
+            err = my_lib.FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv(input1, input2, input3, output)
+        if err != 0:
+            print(err)
+        return output
+
+
+class FilterInterpolationOffsetLayer(_DeformableForward):
+    """FilterInterpolationLayer_gpu_forward (reference FilterInterpolationLayer.py:36)."""
+    variant = "offset"
+
+    @staticmethod
+    def forward(ctx, input1, input2, input3, input4):
+        return FilterInterpolationOffsetLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
+                                                   input4.contiguous())
+
+
+class FilterInterpolationDeforConvLayer(_DeformableForward):
+    """FilterInterpolationLayer_gpu_forward_deforconv (reference FilterInterpolationLayer.py:37)."""
+    variant = "deforconv"
+
+    @staticmethod
+    def forward(ctx, input1, input2, input3, input4):
+        return FilterInterpolationDeforConvLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
+                                                      input4.contiguous())
+
+
+class FilterInterpolationNoFilterLayer(_DeformableForward):
+    """FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv (reference FilterInterpolationLayer.py:38)."""
+    variant = "nofilter"
+
+    @staticmethod
+    def forward(ctx, input1, input2, input3):
+        return FilterInterpolationNoFilterLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
+                                                     None)
