@@ -1,0 +1,537 @@
+"""GPU suite (`-m gpu`): the HIP kernels, called through the C ABI (ctypes) and through the
+reference-named extension modules / wrapper mirrors, against the CPU oracle and the
+committed golden fixtures.
+
+Tolerances (float32):
+  * deterministic ops (FilterInterpolation fwd incl. deformable variants, Interpolation fwd,
+    SeparableConv fwd, SeparableConvFlow, correlation fwd, the per-pixel parts of the
+    backwards): BIT-EXACT against the oracle in fmad=1 mode (same operations, same order,
+    same fused multiply-adds), and <= 1e-5 * max(1, |ref|) against the oracle's strict
+    C-semantics mode and the golden fixtures (the only difference is FMA contraction);
+  * scatter ops (projections fwd, image gradients): `count` bit-exact for FlowProjection,
+    values <= 1e-4 abs (fp32 atomic order); bit-exact on dyadic inputs whose sums are exact
+    in any order; identical hole mask;
+  * correlation against the reference's 32-lane tree order: <= 1e-5 rel.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("`-m gpu` tests need a GPU: torch.cuda.is_available() is False")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def cabi(torch_mod):
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import cabi as c
+    assert "gfx950" in c.version()
+    return c
+
+
+def gpu(torch, a):
+    # torch.tensor copies into canonical dense strides (from_numpy would keep numpy's arbitrary
+    # stride of a size-1 axis, which the bindings' stride checks rightly reject)
+    return torch.tensor(np.asarray(a), device="cuda:0")
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def smooth_flow(rng, b, h, w, sigma):
+    from tests.golden.make_golden import smooth_flow as sf
+    return sf(rng, b, h, w, sigma)
+
+
+def close(a, ref, tol=1e-5):
+    return np.all(np.abs(a - ref) <= tol * np.maximum(1.0, np.abs(ref)))
+
+
+# ------------------------------------------------------------------ FilterInterpolation forward
+
+FI_SHAPES = [(1, 3, 32, 48), (2, 5, 40, 72), (1, 3, 17, 130), (1, 1, 1, 1), (1, 2, 3, 5), (3, 4, 16, 64),
+             (1, 196, 20, 70)]
+
+
+def run_fi(torch, cabi, img, flow, filt, direct=False):
+    out = torch.full_like(img, float("nan"))         # every element must be written
+    assert cabi.filterinterp_forward_ori(img, flow, filt, out, direct=direct) == 0
+    return out
+
+
+@pytest.mark.parametrize("B,C,H,W", FI_SHAPES)
+@pytest.mark.parametrize("flow_kind", ["smooth", "uniform1", "wild", "zero", "border"])
+def test_filterinterp_forward_bit_exact(torch_mod, cabi, oracle, B, C, H, W, flow_kind):
+    torch = torch_mod
+    rng = np.random.default_rng(B * 7 + C * 3 + H + W)
+    img = rng.random((B, C, H, W), dtype=f32)
+    filt = rng.random((B, 16, H, W), dtype=f32)
+    if flow_kind == "smooth":
+        flow = smooth_flow(rng, B, H, W, 3.0)
+    elif flow_kind == "uniform1":
+        flow = rng.uniform(-1, 1, (B, 2, H, W)).astype(f32)
+    elif flow_kind == "wild":
+        flow = rng.uniform(-W / 2, W / 2, (B, 2, H, W)).astype(f32)
+    elif flow_kind == "zero":
+        flow = np.zeros((B, 2, H, W), f32)
+    else:   # every pixel lands exactly on the last row / column or on (0,0): closed bounds, clamped windows
+        flow = np.zeros((B, 2, H, W), f32)
+        flow[:, 0] = (W - 1) - np.arange(W)[None, None, :]
+        flow[:, 1] = (H - 1) - np.arange(H)[None, :, None]
+        flow[:, :, ::2, ::2] *= -0.0
+        flow[:, 0, 1::2] = -np.arange(W)[None, None, :]
+    ref = oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1)
+    strict = oracle.filterinterp_ori_fwd(img, flow, filt, fmad=0)
+    for direct in (False, True):
+        out = cpu(run_fi(torch, cabi, gpu(torch, img), gpu(torch, flow), gpu(torch, filt), direct))
+        assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
+        assert close(out, strict)
+
+
+@pytest.mark.parametrize("fs", [2, 3, 5, 6])
+def test_filterinterp_forward_other_filter_sizes(torch_mod, cabi, oracle, fs):
+    torch = torch_mod
+    rng = np.random.default_rng(fs)
+    B, C, H, W = 2, 3, 24, 70
+    img = rng.random((B, C, H, W), dtype=f32)
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    out = cpu(run_fi(torch, cabi, gpu(torch, img), gpu(torch, flow), gpu(torch, filt)))
+    assert np.array_equal(out, oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1))
+
+
+def test_filterinterp_forward_strided_views(torch_mod, cabi, oracle):
+    """batch / channel / row strides other than dense (the bindings allow any with w stride 1)."""
+    torch = torch_mod
+    rng = np.random.default_rng(9)
+    B, C, H, W = 2, 3, 20, 66
+    big = gpu(torch, rng.random((B, C + 2, H + 3, W + 5), dtype=f32))
+    img = big[:, 1:C + 1, 2:H + 2, 3:W + 3]
+    outbuf = torch.zeros_like(big)
+    out = outbuf[:, 1:C + 1, 2:H + 2, 3:W + 3]
+    fbig = gpu(torch, rng.random((B, 18, H, W + 1), dtype=f32))
+    filt = fbig[:, 1:17, :, :W]
+    flow_np = smooth_flow(rng, B, H, W, 3.0)
+    flow = gpu(torch, flow_np)
+    assert not img.is_contiguous() and not filt.is_contiguous()
+    assert cabi.filterinterp_forward_ori(img, flow, filt, out) == 0
+    ref = oracle.filterinterp_ori_fwd(cpu(img), flow_np, cpu(filt), fmad=1)
+    assert np.array_equal(cpu(out), ref)
+    outbuf[:, 1:C + 1, 2:H + 2, 3:W + 3] = 0
+    assert not outbuf.any()                              # nothing written outside the view
+
+
+def test_filterinterp_binding_checks(torch_mod, cabi):
+    torch = torch_mod
+    img = torch.zeros((1, 3, 8, 8), device="cuda:0")
+    filt = torch.zeros((1, 16, 8, 8), device="cuda:0")
+    out = torch.zeros_like(img)
+    assert cabi.filterinterp_forward_ori(img, torch.zeros((1, 3, 8, 8), device="cuda:0"), filt, out) == 1
+    assert cabi.filterinterp_forward_ori(img, torch.zeros((1, 2, 8, 9), device="cuda:0"), filt, out) == 1
+    assert cabi.filterinterp_forward_ori(img, torch.zeros((2, 2, 8, 8), device="cuda:0"), filt, out) == 1
+    import filterinterpolation_cuda as m
+    assert m.FilterInterpolationLayer_gpu_forward_ori(img, torch.zeros((1, 3, 8, 8), device="cuda:0"), filt, out) == 1
+    with pytest.raises(RuntimeError):
+        cabi.filterinterp_forward_ori(img.cpu(), torch.zeros((1, 2, 8, 8)), filt.cpu(), out.cpu())
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("fs", [4, 6, 3])
+def test_deformable_forward_bit_exact(torch_mod, cabi, oracle, variant, fs):
+    torch = torch_mod
+    rng = np.random.default_rng(40 + variant + fs)
+    B, C, H, W = 2, 3, 24, 70
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 2.0)
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    for scale in (0.5, 3.0):
+        off = rng.uniform(-scale, scale, (B, 2 * fs * fs, H, W)).astype(f32)
+        out = torch.zeros((B, C, H, W), device="cuda:0")
+        if variant == 2:
+            err = cabi.filterinterp_forward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, off), None, out)
+        else:
+            err = cabi.filterinterp_forward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, filt),
+                                                  gpu(torch, off), out)
+        assert err == 0
+        ref = oracle.filterinterp_defor_fwd(variant, img, flow, filt, off, fmad=1)
+        assert np.array_equal(cpu(out), ref)
+
+
+# ------------------------------------------------------------------ projections
+
+@pytest.mark.parametrize("B,H,W", [(1, 32, 48), (2, 17, 70), (1, 1, 1), (1, 40, 200)])
+@pytest.mark.parametrize("fillhole", [0, 1])
+def test_flowprojection_forward(torch_mod, cabi, oracle, B, H, W, fillhole):
+    torch = torch_mod
+    rng = np.random.default_rng(H * W)
+    flow = smooth_flow(rng, B, H, W, 3.0) if H > 1 else np.zeros((B, 2, H, W), f32)
+    for fl, exact in ((flow, False), ((np.round(flow * 8) / 8).astype(f32), True)):
+        count = torch.zeros((B, 1, H, W), device="cuda:0")
+        out = torch.zeros((B, 2, H, W), device="cuda:0")
+        assert cabi.flowprojection_forward(gpu(torch, fl), count, out, fillhole) == 0
+        ref, rcount = oracle.flowproj_fwd(fl, fillhole)
+        assert np.array_equal(cpu(count), rcount)                    # exact small integers
+        if exact:
+            assert np.array_equal(cpu(out), ref)                     # dyadic sums: order-free
+        else:
+            assert np.abs(cpu(out) - ref).max() <= 1e-4
+        assert np.array_equal(cpu(out) == 0, ref == 0) or not exact  # identical hole pattern
+
+
+@pytest.mark.parametrize("fillhole", [0, 1])
+def test_depthflowprojection_forward(torch_mod, cabi, oracle, fillhole):
+    torch = torch_mod
+    rng = np.random.default_rng(3)
+    B, H, W = 2, 33, 70
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    depth = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    count = torch.zeros((B, 1, H, W), device="cuda:0")
+    out = torch.zeros((B, 2, H, W), device="cuda:0")
+    assert cabi.depthflowprojection_forward(gpu(torch, flow), gpu(torch, depth), count, out, fillhole) == 0
+    ref, rcount = oracle.depthflowproj_fwd(flow, depth, fillhole)
+    assert np.array_equal(cpu(count) > 0, rcount > 0)
+    assert close(cpu(count), rcount, 1e-4) and close(cpu(out), ref, 1e-4)
+    # dyadic flow and depth: exact sums -> bit-identical
+    fq = (np.round(flow * 8) / 8).astype(f32)
+    dq = (np.round(depth * 16) / 16 + 1 / 16).astype(f32)
+    count.zero_(), out.zero_()
+    assert cabi.depthflowprojection_forward(gpu(torch, fq), gpu(torch, dq), count, out, fillhole) == 0
+    ref, rcount = oracle.depthflowproj_fwd(fq, dq, fillhole)
+    assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref)
+
+
+def test_projection_edge_cases(torch_mod, cabi, oracle):
+    torch = torch_mod
+    H, W = 12, 70
+    for fl in (np.full((1, 2, H, W), 100.0, f32),                        # everything leaves the frame
+               np.stack([np.full((H, W), 2.0, f32), np.full((H, W), 1.0, f32)])[None]):   # SURVEY case 5
+        for fh in (0, 1):
+            count = torch.zeros((1, 1, H, W), device="cuda:0")
+            out = torch.zeros((1, 2, H, W), device="cuda:0")
+            assert cabi.flowprojection_forward(gpu(torch, fl), count, out, fh) == 0
+            ref, rcount = oracle.flowproj_fwd(fl, fh)
+            assert np.array_equal(cpu(out), ref) and np.array_equal(cpu(count), rcount)
+
+
+def test_projection_backward(torch_mod, cabi, oracle):
+    torch = torch_mod
+    rng = np.random.default_rng(21)
+    B, H, W = 2, 20, 70
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    depth = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    gout = rng.normal(size=(B, 2, H, W)).astype(f32)
+    out, count = oracle.depthflowproj_fwd(flow, depth, 0)
+    cnt = np.where(count > 0, count, 1).astype(f32)
+    g1 = torch.zeros((B, 2, H, W), device="cuda:0")
+    assert cabi.flowprojection_backward(gpu(torch, flow), gpu(torch, cnt), gpu(torch, gout), g1) == 0
+    assert np.array_equal(cpu(g1), oracle.flowproj_bwd(flow, cnt, gout))
+    g1.zero_()
+    g2 = torch.zeros((B, 1, H, W), device="cuda:0")
+    assert cabi.depthflowprojection_backward(gpu(torch, flow), gpu(torch, depth), gpu(torch, cnt), gpu(torch, out),
+                                             gpu(torch, gout), g1, g2) == 0
+    rf, rd = oracle.depthflowproj_bwd(flow, depth, cnt, out, gout)
+    assert np.array_equal(cpu(g1), rf) and np.array_equal(cpu(g2), rd)
+
+
+# ------------------------------------------------------------------ FilterInterpolation backward
+
+def test_filterinterp_backward(torch_mod, cabi, oracle):
+    torch = torch_mod
+    rng = np.random.default_rng(31)
+    for (B, C, H, W, fs) in ((2, 3, 20, 70, 4), (1, 2, 12, 20, 5)):
+        img = rng.random((B, C, H, W), dtype=f32)
+        flow = smooth_flow(rng, B, H, W, 3.0)
+        filt = rng.random((B, fs * fs, H, W), dtype=f32)
+        gout = rng.normal(size=(B, C, H, W)).astype(f32)
+        g1 = torch.zeros((B, C, H, W), device="cuda:0")
+        g2 = torch.zeros((B, 2, H, W), device="cuda:0")
+        g3 = torch.zeros((B, fs * fs, H, W), device="cuda:0")
+        assert cabi.filterinterp_backward_ori(gpu(torch, img), gpu(torch, flow), gpu(torch, filt), gpu(torch, gout),
+                                              g1, g2, g3) == 0
+        r1, r2, r3 = oracle.filterinterp_ori_bwd(img, flow, filt, gout, fmad=1)
+        assert np.abs(cpu(g1) - r1).max() <= 1e-4                   # atomics: order-dependent
+        assert np.array_equal(cpu(g2), r2)                          # per-pixel, deterministic
+        assert np.array_equal(cpu(g3), r3)
+
+
+# ------------------------------------------------------------------ Interpolation / SeparableConv / SeparableConvFlow
+
+def test_interpolation_forward_backward(torch_mod, cabi, oracle):
+    torch = torch_mod
+    rng = np.random.default_rng(41)
+    B, C, H, W = 2, 5, 20, 70
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    flow[0, 0, 0, :] = (W - 0.5) - np.arange(W)                     # x2 in (W-1, W): valid for this op only
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    out = torch.full((B, C, H, W), float("nan"), device="cuda:0")
+    assert cabi.interpolation_forward(gpu(torch, img), gpu(torch, flow), out) == 0
+    assert np.array_equal(cpu(out), oracle.interp_fwd(img, flow, fmad=1))
+    assert cabi.interpolation_forward(gpu(torch, img), gpu(torch, flow), out, require_c3=True) == 1
+    g1 = torch.zeros((B, C, H, W), device="cuda:0")
+    g2 = torch.zeros((B, 2, H, W), device="cuda:0")
+    assert cabi.interpolation_backward(gpu(torch, img), gpu(torch, flow), gpu(torch, gout), g1, g2) == 0
+    r1, r2 = oracle.interp_bwd(img, flow, gout, fmad=1)
+    assert np.abs(cpu(g1) - r1).max() <= 1e-4
+    assert np.array_equal(cpu(g2), r2)
+
+
+@pytest.mark.parametrize("fs", [1, 5, 13])
+def test_separableconv_and_flow(torch_mod, cabi, oracle, fs):
+    torch = torch_mod
+    rng = np.random.default_rng(50 + fs)
+    B, C, H, W = 2, 3, 30, 80
+    oh, ow = H - fs + 1, W - fs + 1
+    img = rng.random((B, C, H, W), dtype=f32)
+    v = rng.random((B, fs, oh, ow), dtype=f32)
+    h = rng.random((B, fs, oh, ow), dtype=f32)
+    v[0, :, 2, 3] = 0
+    gi, gv, gh = gpu(torch, img), gpu(torch, v), gpu(torch, h)
+    out = torch.full((B, C, oh, ow), float("nan"), device="cuda:0")
+    assert cabi.separableconv_forward(gi, gv, gh, out) == 0
+    assert np.array_equal(cpu(out), oracle.sepconv_fwd(img, v, h, fmad=1))
+    fo = torch.full((B, 2, oh, ow), float("nan"), device="cuda:0")
+    assert cabi.separableconvflow_forward(gi, gv, gh, fo) == 0
+    assert np.array_equal(cpu(fo), oracle.sepconvflow_fwd(v, h, H, W, fmad=1))
+    assert cpu(fo)[0, 1, 2, 3] == -2000.0
+    gout = rng.normal(size=(B, C, oh, ow)).astype(f32)
+    g1, g2, g3 = torch.zeros_like(gi), torch.zeros_like(gv), torch.zeros_like(gh)
+    assert cabi.separableconv_backward(gi, gv, gh, gpu(torch, gout), g1, g2, g3) == 0
+    r1, r2, r3 = oracle.sepconv_bwd(img, v, h, gout)
+    assert close(cpu(g1), r1, 1e-4)
+    assert np.array_equal(cpu(g2), r2) and np.array_equal(cpu(g3), r3)
+    gflow = rng.normal(size=(B, 2, oh, ow)).astype(f32)
+    g2.zero_(), g3.zero_()
+    assert cabi.separableconvflow_backward(gi, gv, gh, gpu(torch, gflow), g2, g3) == 0
+    r2, r3 = oracle.sepconvflow_bwd(v, h, gflow, H, W, fmad=1)
+    assert np.array_equal(cpu(g2), r2) and np.array_equal(cpu(g3), r3)
+
+
+# ------------------------------------------------------------------ correlation
+
+@pytest.mark.parametrize("C,H,W,pad,k,md,s1,s2", [(32, 20, 40, 4, 1, 4, 1, 1), (196, 9, 13, 4, 1, 4, 1, 1),
+                                                   (7, 8, 33, 4, 1, 4, 1, 1), (5, 12, 14, 3, 3, 4, 1, 2),
+                                                   (8, 16, 18, 20, 1, 20, 2, 2), (3, 10, 10, 2, 1, 4, 1, 1)])
+def test_correlation_forward(torch_mod, cabi, oracle, C, H, W, pad, k, md, s1, s2):
+    torch = torch_mod
+    rng = np.random.default_rng(C + H)
+    f1 = rng.normal(size=(2, C, H, W)).astype(f32)
+    f2 = rng.normal(size=(2, C, H, W)).astype(f32)
+    out = cpu(cabi.correlation_forward(gpu(torch, f1), gpu(torch, f2), pad, k, md, s1, s2))
+    seq = oracle.correlation_fwd(f1, f2, pad, k, md, s1, s2, order=1, fmad=1)
+    assert out.shape == seq.shape
+    assert np.array_equal(out, seq)                                 # same sequential channel order
+    tree = oracle.correlation_fwd(f1, f2, pad, k, md, s1, s2, order=0, fmad=0)
+    assert close(out, tree, 1e-5)                                   # reference's lane/tree order
+
+
+def test_correlation_backward(torch_mod, cabi, oracle):
+    torch = torch_mod
+    rng = np.random.default_rng(61)
+    for (C, H, W, pad, k, md, s2) in ((6, 9, 33, 4, 1, 4, 1), (3, 8, 8, 4, 3, 4, 2)):
+        f1 = rng.normal(size=(2, C, H, W)).astype(f32)
+        f2 = rng.normal(size=(2, C, H, W)).astype(f32)
+        oc, oh, ow = oracle.correlation_out_dims(H, W, pad, k, md, 1, s2)
+        g = rng.normal(size=(2, oc, oh, ow)).astype(f32)
+        g1, g2 = cabi.correlation_backward(gpu(torch, f1), gpu(torch, f2), gpu(torch, g), pad, k, md, 1, s2)
+        r1, r2 = oracle.correlation_bwd(f1, f2, g, pad, k, md, 1, s2)
+        assert np.array_equal(cpu(g1), r1) and np.array_equal(cpu(g2), r2)
+
+
+# ------------------------------------------------------------------ golden fixtures (no oracle involved)
+
+def test_against_golden_fixtures(torch_mod, cabi, golden_dir):
+    torch = torch_mod
+    g = np.load(os.path.join(golden_dir, "filterinterp.npz"))
+    img, flow, filt, off = (gpu(torch, g[k]) for k in ("fi_img", "fi_flow", "fi_filt", "fi_off"))
+    out = torch.zeros_like(img)
+    assert cabi.filterinterp_forward_ori(img, flow, filt, out) == 0
+    assert close(cpu(out), g["fi_out"])
+    for v, name in ((0, "offset"), (1, "region"), (2, "nofilter")):
+        out.zero_()
+        a3, a4 = (off, None) if v == 2 else (filt, off)
+        assert cabi.filterinterp_forward_defor(v, img, flow, a3, a4, out) == 0
+        assert close(cpu(out), g["fi_out_" + name])
+    out5 = torch.zeros_like(img[:1])
+    assert cabi.filterinterp_forward_ori(img[:1].contiguous(), flow[:1].contiguous(), gpu(torch, g["fi5_filt"]), out5) == 0
+    assert close(cpu(out5), g["fi5_out"])
+    g1, g2, g3 = torch.zeros_like(img), torch.zeros_like(flow), torch.zeros_like(filt)
+    assert cabi.filterinterp_backward_ori(img, flow, filt, gpu(torch, g["fi_gout"]), g1, g2, g3) == 0
+    assert close(cpu(g1), g["fi_gimg"], 1e-4) and close(cpu(g2), g["fi_gflow"], 1e-4) and close(cpu(g3), g["fi_gfilt"], 1e-4)
+
+    g = np.load(os.path.join(golden_dir, "projection.npz"))
+    B, _, H, W = g["flow"].shape
+    for fh in (0, 1):
+        count = torch.zeros((B, 1, H, W), device="cuda:0")
+        out = torch.zeros((B, 2, H, W), device="cuda:0")
+        assert cabi.flowprojection_forward(gpu(torch, g["flow_q"]), count, out, fh) == 0
+        assert np.array_equal(cpu(out), g["outq_fh%d" % fh]) and np.array_equal(cpu(count), g["countq_fh%d" % fh])
+        count.zero_(), out.zero_()
+        assert cabi.flowprojection_forward(gpu(torch, g["flow"]), count, out, fh) == 0
+        assert np.array_equal(cpu(count), g["count_fh%d" % fh]) and np.abs(cpu(out) - g["out_fh%d" % fh]).max() <= 1e-4
+        count.zero_(), out.zero_()
+        assert cabi.depthflowprojection_forward(gpu(torch, g["flow"]), gpu(torch, g["depth"]), count, out, fh) == 0
+        assert close(cpu(out), g["dout_fh%d" % fh], 1e-4) and close(cpu(count), g["dcount_fh%d" % fh], 1e-4)
+
+    g = np.load(os.path.join(golden_dir, "warp_sepconv.npz"))
+    img, flow = gpu(torch, g["img"]), gpu(torch, g["flow"])
+    out = torch.zeros_like(img)
+    assert cabi.interpolation_forward(img, flow, out) == 0
+    assert close(cpu(out), g["out"])
+    v, h = gpu(torch, g["sep_v"]), gpu(torch, g["sep_h"])
+    so = torch.zeros(g["sep_out"].shape, device="cuda:0")
+    assert cabi.separableconv_forward(img, v, h, so) == 0
+    assert close(cpu(so), g["sep_out"])
+    fo = torch.zeros(g["sepflow_out"].shape, device="cuda:0")
+    assert cabi.separableconvflow_forward(img, v, h, fo) == 0
+    assert close(cpu(fo), g["sepflow_out"])
+
+    g = np.load(os.path.join(golden_dir, "correlation.npz"))
+    f1, f2 = gpu(torch, g["f1"]), gpu(torch, g["f2"])
+    assert close(cpu(cabi.correlation_forward(f1, f2, 4, 1, 4, 1, 1)), g["out_pwc"])
+    assert close(cpu(cabi.correlation_forward(f1, f2, 3, 3, 4, 1, 2)), g["out_k3s2"])
+    assert close(cpu(cabi.correlation_forward(f1[:, :8], f2[:, :8], 20, 1, 20, 2, 2)), g["out_flownet"])
+    g1, g2 = cabi.correlation_backward(f1, f2, gpu(torch, g["gout_pwc"]), 4, 1, 4, 1, 1)
+    assert close(cpu(g1), g["g1_pwc"], 1e-4) and close(cpu(g2), g["g2_pwc"], 1e-4)
+
+
+# ------------------------------------------------------------------ extension modules + wrapper mirrors (drop-in path)
+
+def test_wrapper_mirrors_match_cabi(torch_mod, cabi, oracle):
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd.my_package.FilterInterpolation import FilterInterpolationModule, FilterInterpolationDeformableModule
+    from vfidkr_amd.my_package.FlowProjection import FlowProjectionModule
+    from vfidkr_amd.my_package.DepthFlowProjection import DepthFlowProjectionModule
+    from vfidkr_amd.my_package.Interpolation import InterpolationModule
+    from vfidkr_amd.my_package.InterpolationCh import InterpolationChModule
+    from vfidkr_amd.my_package.SeparableConv import SeparableConvModule
+    from vfidkr_amd.my_package.SeparableConvFlow import SeparableConvFlowModule
+    from vfidkr_amd.PWCNet.correlation_package_pytorch1_0.correlation import Correlation
+
+    rng = np.random.default_rng(71)
+    B, C, H, W = 2, 3, 24, 70
+    img_np = rng.random((B, C, H, W), dtype=f32)
+    flow_np = smooth_flow(rng, B, H, W, 3.0)
+    filt_np = rng.random((B, 16, H, W), dtype=f32)
+    off_np = rng.uniform(-1, 1, (B, 32, H, W)).astype(f32)
+    depth_np = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    img = gpu(torch, img_np).requires_grad_(True)
+    flow = gpu(torch, flow_np).requires_grad_(True)
+    filt = gpu(torch, filt_np).requires_grad_(True)
+
+    out = FilterInterpolationModule()(img, flow, filt)
+    assert np.array_equal(cpu(out), oracle.filterinterp_ori_fwd(img_np, flow_np, filt_np, fmad=1))
+    gout_np = rng.normal(size=(B, C, H, W)).astype(f32)
+    out.backward(gpu(torch, gout_np))
+    r1, r2, r3 = oracle.filterinterp_ori_bwd(img_np, flow_np, filt_np, gout_np, fmad=1)
+    assert np.abs(cpu(img.grad) - r1).max() <= 1e-4
+    assert np.array_equal(cpu(flow.grad), r2) and np.array_equal(cpu(filt.grad), r3)
+
+    for mode, variant in (("offset", 0), ("deforconv", 1), ("nofilter", 2)):
+        m = FilterInterpolationDeformableModule(mode)
+        with torch.no_grad():
+            o = m(img, flow, gpu(torch, off_np)) if variant == 2 else m(img, flow, filt, gpu(torch, off_np))
+        assert np.array_equal(cpu(o), oracle.filterinterp_defor_fwd(variant, img_np, flow_np, filt_np, off_np, fmad=1))
+
+    fq = (np.round(flow_np * 8) / 8).astype(f32)
+    # requires_grad=False -> fillhole (inference); True -> no fillhole (FlowProjectionLayer.py:23)
+    for rg, fh in ((False, 1), (True, 0)):
+        o = FlowProjectionModule(rg)(gpu(torch, fq))
+        assert np.array_equal(cpu(o), oracle.flowproj_fwd(fq, fh)[0])
+        o = DepthFlowProjectionModule(rg)(gpu(torch, flow_np), gpu(torch, depth_np))
+        assert close(cpu(o), oracle.depthflowproj_fwd(flow_np, depth_np, fh)[0], 1e-4)
+    fl = gpu(torch, flow_np).requires_grad_(True)
+    o = FlowProjectionModule(True)(fl)
+    o.backward(torch.ones_like(o))
+    assert fl.grad is not None and torch.isfinite(fl.grad).all()     # a source's own targets have count >= 1
+
+    with torch.no_grad():
+        assert np.array_equal(cpu(InterpolationModule()(img, flow)), oracle.interp_fwd(img_np, flow_np, fmad=1))
+        img5 = gpu(torch, np.concatenate([img_np, img_np[:, :2]], 1))
+        assert np.array_equal(cpu(InterpolationChModule()(img5, flow))[:, :3], oracle.interp_fwd(img_np, flow_np, fmad=1))
+        fs = 5
+        v_np = rng.random((B, fs, H - fs + 1, W - fs + 1), dtype=f32)
+        h_np = rng.random((B, fs, H - fs + 1, W - fs + 1), dtype=f32)
+        o = SeparableConvModule(fs)(img, gpu(torch, v_np), gpu(torch, h_np))
+        assert np.array_equal(cpu(o), oracle.sepconv_fwd(img_np, v_np, h_np, fmad=1))
+        o = SeparableConvFlowModule(fs)(img, gpu(torch, v_np), gpu(torch, h_np))
+        assert np.array_equal(cpu(o), oracle.sepconvflow_fwd(v_np, h_np, H, W, fmad=1))
+        f1 = rng.normal(size=(B, 32, 12, 20)).astype(f32)
+        f2 = rng.normal(size=(B, 32, 12, 20)).astype(f32)
+        o = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)(
+            gpu(torch, f1), gpu(torch, f2))
+        assert np.array_equal(cpu(o), oracle.correlation_fwd(f1, f2, 4, 1, 4, 1, 1, order=1, fmad=1))
+    a = gpu(torch, f1).requires_grad_(True)
+    b = gpu(torch, f2).requires_grad_(True)
+    o = Correlation(4, 1, 4, 1, 1, 1)(a, b)
+    g = rng.normal(size=tuple(o.shape)).astype(f32)
+    o.backward(gpu(torch, g))
+    r1, r2 = oracle.correlation_bwd(f1, f2, g, 4, 1, 4, 1, 1)
+    assert np.array_equal(cpu(a.grad), r1) and np.array_equal(cpu(b.grad), r2)
+
+
+def test_no_cpu_fallback(torch_mod):
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd.my_package.FilterInterpolation import FilterInterpolationModule
+    with pytest.raises(RuntimeError):
+        FilterInterpolationModule()(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8), torch.zeros(1, 16, 8, 8))
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties + sampled oracle checks
+
+def test_full_size_1080p(torch_mod, cabi, oracle):
+    """cfg3 padded 1152x1984: LDS path == direct path bit for bit on the whole frame (two
+    independent code paths), oracle on C=3 and on sampled channels of C=196, identity and
+    projection invariants."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import synthetic as S
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    frame = S.frames(1, H, W, gen)
+    filt = S.filters(1, H, W, gen)
+    for model in ("smooth", "quarter"):
+        flow = S.flow(1, H, W, 8.0, gen, model)
+        gi, gf, gk = frame.cuda(), flow.cuda(), filt.cuda()
+        a = run_fi(torch, cabi, gi, gf, gk, direct=False)
+        b = run_fi(torch, cabi, gi, gf, gk, direct=True)
+        assert torch.equal(a, b)
+        ref = oracle.filterinterp_ori_fwd(frame.numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8)
+        assert np.array_equal(cpu(a), ref)
+        # projection: count is exact; every valid source adds 4
+        count = torch.zeros((1, 1, H, W), device="cuda:0")
+        out = torch.zeros((1, 2, H, W), device="cuda:0")
+        assert cabi.flowprojection_forward(gf, count, out, 1) == 0
+        rout, rcount = oracle.flowproj_fwd(flow.numpy(), 1)
+        assert np.array_equal(cpu(count), rcount)
+        assert np.abs(cpu(out) - rout).max() <= 1e-4
+        xs = torch.arange(W)[None, :] + flow[0, 0]
+        ys = torch.arange(H)[:, None] + flow[0, 1]
+        nvalid = int(((xs >= 0) & (ys >= 0) & (xs <= W - 1) & (ys <= H - 1)).sum())
+        assert float(count.double().sum()) == 4.0 * nvalid
+    # 196-channel context tensor (DAIN_slowmotion): LDS == direct, oracle on sampled channels
+    ctx = S.context(1, 196, H, W, gen)
+    gc = ctx.cuda()
+    a = run_fi(torch, cabi, gc, gf, gk, direct=False)
+    b = run_fi(torch, cabi, gc, gf, gk, direct=True)
+    assert torch.equal(a, b)
+    sel = [0, 1, 97, 98, 195]
+    ref = oracle.filterinterp_ori_fwd(ctx[:, sel].numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8)
+    assert np.array_equal(cpu(a[:, sel]), ref)
+    # identity: zero flow + one-hot tap (1,1) returns the input exactly
+    onehot = torch.zeros_like(gk)
+    onehot[:, 5] = 1
+    assert torch.equal(run_fi(torch, cabi, gc, torch.zeros_like(gf), onehot), gc)

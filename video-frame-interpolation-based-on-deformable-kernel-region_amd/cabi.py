@@ -82,12 +82,16 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _stream(t):
+def _dev(t):
     if not t.is_cuda:
         raise RuntimeError("vfidkr_amd.cabi: tensors must live on the GPU (there is no CPU path)")
     if t.dtype != torch.float32:
         raise RuntimeError("vfidkr_amd.cabi: tensors must be float32")
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return t.device
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(_dev(t)).cuda_stream)
 
 
 def _finish(err):
@@ -114,7 +118,7 @@ def filterinterp_forward_ori(input1, input2, input3, output, direct=False):
     if dims is None:
         return 1
     b, c, h, w = dims
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         fn = lib().vfi_filterinterp_forward_ori_direct if direct else lib().vfi_filterinterp_forward_ori
         return _finish(fn(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c, h, w, input3.size(1),
                           _st(input1), _st(input2), _st(input3), _stream(input1)))
@@ -129,7 +133,7 @@ def filterinterp_backward_ori(input1, input2, input3, gradoutput, gradinput1, gr
     if input3.stride(1) != gradinput3.stride(1):
         return 1
     b, c, h, w = dims
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_filterinterp_backward_ori(
             _ptr(input1), _ptr(input2), _ptr(input3), _ptr(gradoutput), _ptr(gradinput1), _ptr(gradinput2),
             _ptr(gradinput3), b, c, h, w, input3.size(1), _st(input1), _st(input2), _st(input3), _stream(input1)))
@@ -149,7 +153,7 @@ def filterinterp_forward_defor(variant, input1, input2, input3, input4, output):
             return 1
         fs = int(math.sqrt(input3.size(1)))
         p4, s4 = _ptr(input4), _st(input4)
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_filterinterp_forward_defor(
             variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(output), b, c, h, w, fs, _st(input1),
             _st(input2), _st(input3), s4, _stream(input1)))
@@ -163,7 +167,7 @@ def flowprojection_forward(input1, count, output, fillhole):
     if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
         return 1
     b, _, h, w = input1.shape
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_flowprojection_forward(_ptr(input1), _ptr(count), _ptr(output), b, h, w,
                                                         int(fillhole), _st(input1), _st(count), _stream(input1)))
 
@@ -174,7 +178,7 @@ def flowprojection_backward(input1, count, gradoutput, gradinput1):
         return 1
     if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
         return 1
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_flowprojection_backward(_ptr(input1), _ptr(count), _ptr(gradoutput),
                                                          _ptr(gradinput1), b, h, w, _st(input1), _st(count),
                                                          _stream(input1)))
@@ -186,7 +190,7 @@ def depthflowprojection_forward(input1, input2, count, output, fillhole):
     if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
         return 1
     b, _, h, w = input1.shape
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_depthflowprojection_forward(
             _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), b, h, w, int(fillhole), _st(input1), _st(input2),
             _st(count), _stream(input1)))
@@ -198,7 +202,7 @@ def depthflowprojection_backward(input1, input2, count, output, gradoutput, grad
         return 1
     if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
         return 1
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_depthflowprojection_backward(
             _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), _ptr(gradoutput), _ptr(gradinput1),
             _ptr(gradinput2), b, h, w, _st(input1), _st(input2), _st(count), _stream(input1)))
@@ -214,7 +218,7 @@ def interpolation_forward(input1, input2, output, require_c3=False):
         return 1
     if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
         return 1
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_interpolation_forward(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w,
                                                        _st(input1), _st(input2), _stream(input1)))
 
@@ -229,7 +233,7 @@ def interpolation_backward(input1, input2, gradoutput, gradinput1, gradinput2, r
         return 1
     if input2.stride(0) != gradinput2.stride(0) or input2.stride(1) != gradinput2.stride(1):
         return 1
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_interpolation_backward(_ptr(input1), _ptr(input2), _ptr(gradoutput),
                                                         _ptr(gradinput1), _ptr(gradinput2), b, c, h, w, _st(input1),
                                                         _st(input2), _stream(input1)))
@@ -256,7 +260,7 @@ def separableconv_forward(input1, input2, input3, output):
     if dims is None or output.stride(3) != 1:
         return 1
     b, c, h, w, fs = dims
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_separableconv_forward(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c,
                                                        h, w, fs, _st(input1), _st(input2), _st(input3), _st(output),
                                                        _stream(input1)))
@@ -267,7 +271,7 @@ def separableconv_backward(input1, input2, input3, gradoutput, gradinput1, gradi
     if dims is None or gradoutput.stride(3) != 1:
         return 1
     b, c, h, w, fs = dims
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_separableconv_backward(
             _ptr(input1), _ptr(input2), _ptr(input3), _ptr(gradoutput), _ptr(gradinput1), _ptr(gradinput2),
             _ptr(gradinput3), b, c, h, w, fs, _st(input1), _st(input2), _st(input3), _st(gradoutput),
@@ -279,7 +283,7 @@ def separableconvflow_forward(input1, input2, input3, flow_output):
     if dims is None or flow_output.stride(3) != 1:
         return 1
     b, c, h, w, fs = dims
-    with torch.cuda.device(input2.device):
+    with torch.cuda.device(_dev(input2)):
         return _finish(lib().vfi_separableconvflow_forward(_ptr(input2), _ptr(input3), _ptr(flow_output), b, h, w,
                                                            fs, _st(input2), _st(input3), _st(flow_output),
                                                            _stream(input2)))
@@ -290,7 +294,7 @@ def separableconvflow_backward(input1, input2, input3, gradflow_output, gradinpu
     if dims is None or gradflow_output.stride(3) != 1:
         return 1
     b, c, h, w, fs = dims
-    with torch.cuda.device(input2.device):
+    with torch.cuda.device(_dev(input2)):
         return _finish(lib().vfi_separableconvflow_backward(
             _ptr(input2), _ptr(input3), _ptr(gradflow_output), _ptr(gradinput2), _ptr(gradinput3), b, h, w, fs,
             _st(input2), _st(input3), _st(gradflow_output), _stream(input2)))
@@ -313,7 +317,7 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
     b, c, h, w = input1.shape
     oc, oh, ow = correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2)
     output = torch.empty((b, oc, oh, ow), dtype=torch.float32, device=input1.device)
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         err = lib().vfi_correlation_forward(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w, pad_size,
                                             kernel_size, max_displacement, stride1, stride2, _stream(input1))
     if err != 0:
@@ -325,7 +329,7 @@ def correlation_backward(input1, input2, gradoutput, pad_size, kernel_size, max_
     input1, input2, gradoutput = input1.contiguous(), input2.contiguous(), gradoutput.contiguous()
     b, c, h, w = input1.shape
     g1, g2 = torch.empty_like(input1), torch.empty_like(input2)
-    with torch.cuda.device(input1.device):
+    with torch.cuda.device(_dev(input1)):
         err = lib().vfi_correlation_backward(_ptr(input1), _ptr(input2), _ptr(gradoutput), _ptr(g1), _ptr(g2), b, c,
                                              h, w, pad_size, kernel_size, max_displacement, stride1, stride2,
                                              _stream(input1))

@@ -11,8 +11,10 @@
 // build copies the resulting shared object under the eight module names.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// torch-ROCm tensors carry DeviceType::CUDA ("masquerading"): the guard and the stream
+// accessor have to be the *MasqueradingAsCUDA flavours, the plain c10::hip ones reject them
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cmath>
 
@@ -25,13 +27,13 @@ inline const float* cptr(const at::Tensor& t) { return t.data_ptr<float>(); }
 inline float* mptr(at::Tensor& t) { return t.data_ptr<float>(); }
 
 struct StreamScope {
-    c10::hip::OptionalHIPGuard guard;
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
     vfi_stream_t stream;
     explicit StreamScope(const at::Tensor& t) {
         TORCH_CHECK(t.is_cuda(), "expected a GPU tensor");
         TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32 tensors");
         guard.set_device(t.device());
-        stream = (vfi_stream_t)c10::hip::getCurrentHIPStream(t.get_device()).stream();
+        stream = (vfi_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
     }
 };
 
