@@ -42,6 +42,11 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """Threads for the OpenMP loops of filterinterp_ori_fwd (nthreads < 1) and correlation_fwd."""
+    lib().vfi_oracle_set_num_threads(int(n))
+
+
 def _p(a):
     return a.ctypes.data_as(_F)
 

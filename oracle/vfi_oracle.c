@@ -24,6 +24,12 @@
 
 typedef long long i64;
 
+/* threads used by the OpenMP loops of the deterministic per-pixel ops (cpu_baseline timing);
+ * scatter ops stay sequential so their summation order is fixed */
+static int g_threads = 1;
+void vfi_oracle_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int vfi_oracle_get_num_threads(void) { return g_threads; }
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline int mini(int a, int b) { return a < b ? a : b; }
 static inline int maxi(int a, int b) { return a > b ? a : b; }
@@ -102,10 +108,11 @@ int vfi_oracle_filterinterp_ori_fwd(const float* img, const float* flow, const f
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || filt_ch <= 0) return 1;
     const int fs = (int)sqrtf((float)filt_ch);            /* filterinterpolation_cuda.cc:556-557 */
     const i64 HW = (i64)H * W;
-    (void)nthreads;
 #ifdef _OPENMP
-    if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for collapse(2) schedule(static) num_threads(nthreads)
+    if (nthreads < 1) nthreads = g_threads;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4) num_threads(nthreads)
+#else
+    (void)nthreads;
 #endif
     for (int b = 0; b < B; ++b) {
         for (int y = 0; y < H; ++y) {
@@ -701,6 +708,9 @@ int vfi_oracle_correlation_fwd(const float* f1, const float* f2, float* out,
     const int dr = md / s2;
     const int dsz = 2 * dr + 1;
     const int nelems = k * k * C;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 2) num_threads(g_threads)
+#endif
     for (int b = 0; b < B; ++b)
     for (int oy = 0; oy < oH; ++oy)
     for (int ox = 0; ox < oW; ++ox) {

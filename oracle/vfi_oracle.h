@@ -28,6 +28,10 @@
 extern "C" {
 #endif
 
+/* threads for the OpenMP loops of A1 (when its nthreads argument is < 1) and A8 forward */
+void vfi_oracle_set_num_threads(int n);
+int vfi_oracle_get_num_threads(void);
+
 /* A1  filterinterpolation_cuda_kernel.cu:2692-2823 (+ cc:537-606) */
 int vfi_oracle_filterinterp_ori_fwd(const float* img, const float* flow, const float* filt,
                                     float* out, int B, int C, int H, int W, int filt_ch,

@@ -40,9 +40,13 @@ def cabi(torch_mod):
 
 
 def gpu(torch, a):
-    # torch.tensor copies into canonical dense strides (from_numpy would keep numpy's arbitrary
-    # stride of a size-1 axis, which the bindings' stride checks rightly reject)
-    return torch.tensor(np.asarray(a), device="cuda:0")
+    # copy into a freshly allocated tensor: canonical dense strides whatever numpy's layout was
+    # (from_numpy / torch.tensor keep a transposed layout or the arbitrary stride of a size-1
+    # axis, which the bindings' stride checks rightly reject)
+    a = np.asarray(a)
+    t = torch.empty(a.shape, dtype=torch.float32, device="cuda:0")
+    t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return t
 
 
 def cpu(t):

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Per-op timing on the GPU (HIP events on the launch stream), for kernel development.
+
+    python tools/bench_ops.py [--ops fi196,fi3,proj,dproj,corr] [--flows smooth,quarter] [--iters 20]
+Prints one line per (op, flow): mean ms and algorithmic GB/s (SURVEY.md 8d byte counts).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import vfidkr_amd  # noqa: E402,F401
+from vfidkr_amd import cabi, synthetic as S  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ops", default="fi196,fi3,proj,dproj,corr")
+    ap.add_argument("--flows", default="smooth,quarter")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    h, w = S.padded_size(args.height, args.width)
+    px = h * w
+    gen = S.generator()
+    frame = S.frames(1, h, w, gen).to(dev)
+    ctx = S.context(1, 196, h, w, gen).to(dev)
+    filt = S.filters(1, h, w, gen).to(dev)
+    depth = S.depth_weight(1, h, w, gen).to(dev)
+    out196, out3 = torch.empty_like(ctx), torch.empty_like(frame)
+    count = torch.zeros((1, 1, h, w), device=dev)
+    proj = torch.zeros((1, 2, h, w), device=dev)
+    ops = args.ops.split(",")
+    for model in args.flows.split(","):
+        flow = S.flow(1, h, w, 8.0 * w / 1984.0, gen, model).to(dev)
+        for direct in (False, True):
+            tag = "direct" if direct else "lds"
+            if "fi196" in ops:
+                ms = timed(lambda: cabi.filterinterp_forward_ori(ctx, flow, filt, out196, direct=direct), args.iters)
+                print("fi196 %-8s %-6s %8.4f ms %8.1f GB/s" % (model, tag, ms, 1640.0 * px / ms / 1e6), flush=True)
+            if "fi3" in ops:
+                ms = timed(lambda: cabi.filterinterp_forward_ori(frame, flow, filt, out3, direct=direct), args.iters * 5)
+                print("fi3   %-8s %-6s %8.4f ms %8.1f GB/s" % (model, tag, ms, 96.0 * px / ms / 1e6), flush=True)
+
+        def fp():
+            count.zero_()
+            proj.zero_()
+            cabi.flowprojection_forward(flow, count, proj, 1)
+
+        def dfp():
+            count.zero_()
+            proj.zero_()
+            cabi.depthflowprojection_forward(flow, depth, count, proj, 1)
+        if "proj" in ops:
+            ms = timed(fp, args.iters * 2)
+            print("proj  %-8s        %8.4f ms %8.1f GB/s (incl. 2 zero fills)" % (model, ms, 20.0 * px / ms / 1e6), flush=True)
+        if "dproj" in ops:
+            ms = timed(dfp, args.iters * 2)
+            print("dproj %-8s        %8.4f ms %8.1f GB/s (incl. 2 zero fills)" % (model, ms, 24.0 * px / ms / 1e6), flush=True)
+    if "corr" in ops:
+        tot_ms, tot_b = 0.0, 0.0
+        for a, b in S.correlation_features(1, h, w, gen):
+            a, b = a.to(dev), b.to(dev)
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            nb = (2 * a.shape[1] + 81) * 4.0 * a.shape[2] * a.shape[3]
+            tot_ms += ms
+            tot_b += nb
+            print("corr  C=%-3d %4dx%-4d   %8.4f ms %8.1f GB/s" % (a.shape[1], a.shape[2], a.shape[3], ms, nb / ms / 1e6), flush=True)
+        print("corr  5 levels         %8.4f ms %8.1f GB/s" % (tot_ms, tot_b / tot_ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()

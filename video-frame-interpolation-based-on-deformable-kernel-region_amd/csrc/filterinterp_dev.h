@@ -17,24 +17,35 @@ __device__ __forceinline__ float fi4_pixel(const float (&v)[16], const float (&f
     return blend4(alpha, beta, TL, TR, BL, BR);
 }
 
-// channel loop of one valid pixel gathering straight from global memory
+// channel loop of one valid pixel gathering straight from global memory.  Row by row, so the
+// register need is 4 taps + 4 sums (the compiler may still batch rows when it has registers
+// to spare); the operation order per quadrant is that of fi4_pixel.
 __device__ __forceinline__ void fi4_channels_direct(const float* __restrict__ img, float* __restrict__ dst,
                                                     int c0, int c1, int64_t cs, int hs, int h, int w,
                                                     int L, int T, const float (&f)[16], float alpha, float beta) {
-    int ro[4], co[4];
+    // unsigned 32-bit element offsets from a wave-uniform plane pointer: the loads take the
+    // scalar-base + vector-offset form, one VGPR per address
+    unsigned ro[4], co[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        ro[k] = clampi(T + k, 0, h - 1) * hs;
-        co[k] = clampi(L + k, 0, w - 1);
+        ro[k] = (unsigned)(clampi(T + k, 0, h - 1) * hs);
+        co[k] = (unsigned)clampi(L + k, 0, w - 1);
     }
     for (int c = c0; c < c1; ++c) {
         const float* p = img + (int64_t)c * cs;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[r * 4 + k] = p[ro[r] + co[k]];
-        dst[(int64_t)c * cs] = fi4_pixel(v, f, alpha, beta);
+        float a0 = p[ro[0] + co[0]], a1 = p[ro[0] + co[1]], a2 = p[ro[0] + co[2]], a3 = p[ro[0] + co[3]];
+        float TL = a0 * f[0];  TL = fmaf(a1, f[1], TL);
+        float TR = a2 * f[2];  TR = fmaf(a3, f[3], TR);
+        a0 = p[ro[1] + co[0]]; a1 = p[ro[1] + co[1]]; a2 = p[ro[1] + co[2]]; a3 = p[ro[1] + co[3]];
+        TL = fmaf(a0, f[4], TL);  TL = fmaf(a1, f[5], TL);
+        TR = fmaf(a2, f[6], TR);  TR = fmaf(a3, f[7], TR);
+        a0 = p[ro[2] + co[0]]; a1 = p[ro[2] + co[1]]; a2 = p[ro[2] + co[2]]; a3 = p[ro[2] + co[3]];
+        float BL = a0 * f[8];   BL = fmaf(a1, f[9], BL);
+        float BR = a2 * f[10];  BR = fmaf(a3, f[11], BR);
+        a0 = p[ro[3] + co[0]]; a1 = p[ro[3] + co[1]]; a2 = p[ro[3] + co[2]]; a3 = p[ro[3] + co[3]];
+        BL = fmaf(a0, f[12], BL);  BL = fmaf(a1, f[13], BL);
+        BR = fmaf(a2, f[14], BR);  BR = fmaf(a3, f[15], BR);
+        dst[(int64_t)c * cs] = blend4(alpha, beta, TL, TR, BL, BR);
     }
 }
 

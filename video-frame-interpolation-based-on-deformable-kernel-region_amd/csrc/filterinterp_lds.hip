@@ -8,14 +8,21 @@
 // pixel and channel; for the 196-channel context tensors of DAIN_slowmotion
 // that is the whole run time.  Here a workgroup owns a 64x16 tile of output
 // pixels (one wave = one 64-pixel row: flow, the 16 filter planes and the output
-// move as full 256-B rows), finds the bounding box of all its taps from the
-// flow, and per channel stages exactly that window of the image plane into LDS
-// with coalesced row reads (borders replicated while staging, so a pixel's 4x4
-// window is always 4 contiguous floats x 4 rows in LDS).  The 16 taps then are
-// LDS reads at immediate offsets.  Flow, blend weights, the 16 filter taps and
-// the LDS row addresses stay in registers for all channels.  The window of
-// channel c+1 is in flight (global -> registers) while channel c is computed
-// (double-buffered LDS, one barrier per channel).
+// move as full 256-B rows; every thread owns FI_PX pixels of one column), finds
+// the bounding box of all its taps from the flow, and per channel stages exactly
+// that window of the image plane into LDS with coalesced row reads (borders
+// replicated while staging, so a pixel's 4x4 window is always 4 contiguous floats
+// x 4 rows in LDS).  The 16 taps then are LDS reads at immediate offsets.  Flow,
+// blend weights, the 16 filter taps and the LDS window address stay in registers
+// for all channels.
+//
+// Pipeline: the op streams every image plane once, so it lives on memory-level
+// parallelism.  Windows are staged by LDS-DMA (global_load_lds_dword: global ->
+// LDS, no staging registers) into a ring of R slots carved from one 64 KB LDS
+// array; while channel c is computed, the windows of channels c+1 .. c+R-1 are in
+// flight or landed.  Per channel: compute, issue the DMA of channel c+R-1 into
+// the slot freed last iteration, counted s_waitcnt vmcnt(N) for channel c+1 only,
+// one raw s_barrier.  R-1 windows in flight per workgroup, two workgroups per CU.
 //
 // A tile whose tap window does not fit the LDS budget (wildly divergent flow)
 // gathers from global memory instead -- same results, decided per workgroup.
@@ -23,19 +30,37 @@
 // Launch: 1-D grid; block b -> tile so that the blocks of one XCD (b % 8) own a
 // contiguous band of tiles: neighbouring tiles re-read each other's halo rows
 // from the same L2.  An optional split of the channel range over blockIdx.y
-// shortens the tail when tiles * 1 does not fill the chip evenly.
+// shortens the tail when the tile count does not fill the chip evenly.
 #include "filterinterp_dev.h"
 
 #include <limits.h>
 
+#include <type_traits>
+
 namespace vfi {
+
+// compile-time loop: the body sees a constant index, so register arrays indexed by it stay in
+// registers (a runtime-indexed array would be demoted to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 #define FI_TW 64
 #define FI_TH 16
-#define FI_THREADS (FI_TW * FI_TH)
-#define FI_CAP 8000                 // floats per LDS buffer (2 buffers = 64,000 B)
-#define FI_NPT ((FI_CAP + FI_THREADS - 1) / FI_THREADS)
+#define FI_PX 2                                     // pixels per thread (rows y and y + FI_TH/FI_PX)
+#define FI_THREADS (FI_TW * FI_TH / FI_PX)          // 512
+#define FI_PASS_ROWS (FI_TH / FI_PX)
+#define FI_HDR 16                                   // floats at the head of the LDS array (bounding box)
+#define FI_RING_FLOATS 15984                        // LDS ring: 16000 floats = 64,000 B with the header
+#define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
+#define FI_KTOP 15                                  // staged elements per thread and channel, at most
 #define FI_XCDS 8
+
+typedef __attribute__((address_space(3))) void* fi_lptr_t;
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -48,13 +73,110 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(FI_THREADS) void fi_forward_ori_lds(
+struct FiWindow { int bx0, by0, bw, n, h, w, hs; };
+struct FiPixel {
+    bool valid, inimg;
+    float alpha, beta;
+    int lbase;              // LDS index of the pixel's 4x4 window origin inside a staged window
+    unsigned pix;           // element offset of the pixel inside an image plane
+    float f[16];
+};
+
+// s_waitcnt vmcnt(G*K): everything but the youngest G staged windows (K DMA loads each) has landed.
+// The pixel stores of the compute phases sit in the same in-order counter; not counting them
+// only makes the wait stricter.
+template <int K>
+__device__ __forceinline__ void fi_wait_windows(int younger_groups) {
+    switch (younger_groups) {
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K) : "memory"); break;
+    }
+}
+
+// Channel loop of one workgroup: K staged elements per thread and channel, ring of R slots.
+template <int K>
+__device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
+                                                int c_begin, int c_end, int tid, const FiWindow& win,
+                                                const FiPixel (&px)[FI_PX], float* __restrict__ ring, int R) {
+    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+    // element e = tid + k*FI_THREADS of the window, row-major with row length bw.  Elements past
+    // the window (e >= n) re-read element 0 and land in the slot's slack, so the DMA loads are
+    // unconditional straight-line code.  Addressing is buffer-style: a wave-uniform descriptor of
+    // the channel's plane (rebuilt per channel from scalars) + one 32-bit byte offset per element
+    // that never changes -- no per-channel vector address arithmetic, one VGPR per element.  One
+    // buffer_load_dword ... lds writes 64 consecutive floats: LDS destination = wave-uniform base
+    // + lane*4, which is exactly this flat layout.
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int e = tid + k * FI_THREADS;
+        e = (e < win.n) ? e : 0;
+        const int r = (win.bw > 0) ? e / win.bw : 0;
+        const int col = e - r * win.bw;
+        goff[k] = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+    }
+    const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
+    constexpr int NP = K * FI_THREADS;                      // floats per ring slot
+    const int D = R - 1;                                    // windows in flight
+    auto issue = [&](int c, int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
+        float* l = ring + slot * NP + tid;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS), 4, goff[k], 0, 0, 0);
+    };
+    auto compute = [&](int c, int slot) {
+        float* o = out + (int64_t)c * cs;
+        const float* base = ring + slot * NP;
+#pragma unroll
+        for (int p = 0; p < FI_PX; ++p) {
+            if (px[p].valid) {
+                const float* t = base + px[p].lbase;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.bw + k];
+                o[px[p].pix] = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+            }
+        }
+    };
+
+    if (c_begin >= c_end) return;
+    const int last = c_end - 1;
+    for (int j = 0; j < D; ++j)
+        if (c_begin + j <= last) issue(c_begin + j, j);
+    fi_wait_windows<K>(min(c_begin + D - 1, last) - c_begin);      // window of c_begin has landed ...
+    __builtin_amdgcn_s_barrier();                                   // ... in every wave
+    int slot = 0;
+    for (int c = c_begin; c <= last; ++c) {
+        compute(c, slot);
+        // the slot read in the previous iteration is free: every wave passed that barrier
+        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
+        if (c < last) fi_wait_windows<K>(min(c + D, last) - (c + 1));
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    // copy-through of the (rare) invalid pixels (:2814-2818), kept out of the pipelined loop so
+    // that the loop's only vector-memory loads are the staged windows
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p)
+        if (px[p].inimg && !px[p].valid)
+            for (int c = c_begin; c < c_end; ++c) out[(int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+}
+
+// two 512-thread workgroups per CU (4 waves per SIMD): at most 128 VGPRs
+__global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3,
     int tiles_x, int tiles_y, int ntiles, int per_xcd, int ch_per_group) {
-    __shared__ float buf[2][FI_CAP];
-    __shared__ int box[4];
+    // ONE LDS array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt
+    // before LDS reads): 16-float header holding the bounding box, then the window ring
+    __shared__ float lds[FI_HDR + FI_RING_FLOATS];
+    int* box = reinterpret_cast<int*>(lds);
 
     // ---- block -> tile (XCD-contiguous bands)
     const int bid = blockIdx.x;
@@ -68,32 +190,45 @@ __global__ __launch_bounds__(FI_THREADS) void fi_forward_ori_lds(
 
     const int tid = threadIdx.x;
     const int x = txi * FI_TW + (tid & (FI_TW - 1));
-    const int y = tyi * FI_TH + (tid >> 6);
-    const bool inimg = x < w && y < h;
+    const int y0 = tyi * FI_TH + (tid >> 6);
 
-    // ---- this thread's pixel: flow, validity, window origin, blend weights
-    float fx = 0.0f, fy = 0.0f;
-    if (inimg) {
-        const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
-        fx = flow[0];
-        fy = flow[s2.c];
+    // ---- this thread's pixels: flow, validity, window origin, blend weights
+    FiPixel px[FI_PX];
+    int L[FI_PX], T[FI_PX];
+    int bx_lo = INT_MAX, by_lo = INT_MAX, bx_hi = INT_MIN, by_hi = INT_MIN;
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p) {
+        const int y = y0 + p * FI_PASS_ROWS;
+        px[p].inimg = x < w && y < h;
+        px[p].pix = (unsigned)(y * (int)s1.h + x);
+        float fx = 0.0f, fy = 0.0f;
+        if (px[p].inimg) {
+            const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+            fx = flow[0];
+            fy = flow[s2.c];
+        }
+        const float x2 = (float)x + fx;
+        const float y2 = (float)y + fy;
+        px[p].valid = px[p].inimg && fi_valid(fx, fy, x2, y2, w, h);
+        const int ix = px[p].valid ? (int)x2 : 0, iy = px[p].valid ? (int)y2 : 0;
+        L[p] = ix - 1;                                      // ix + 1 - fs/2, fs == 4
+        T[p] = iy - 1;
+        px[p].alpha = x2 - (float)ix;
+        px[p].beta = y2 - (float)iy;
+        if (px[p].valid) {
+            bx_lo = min(bx_lo, L[p]); by_lo = min(by_lo, T[p]);
+            bx_hi = max(bx_hi, L[p] + 3); by_hi = max(by_hi, T[p] + 3);
+        }
     }
-    const float x2 = (float)x + fx;
-    const float y2 = (float)y + fy;
-    const bool valid = inimg && fi_valid(fx, fy, x2, y2, w, h);
-    const int ix = valid ? (int)x2 : 0, iy = valid ? (int)y2 : 0;
-    const int L = ix - 1, T = iy - 1;                       // ix + 1 - fs/2, fs == 4
-    const float alpha = x2 - (float)ix;
-    const float beta = y2 - (float)iy;
 
     // ---- bounding box of every tap of the tile (unclamped window coordinates)
     if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
     __syncthreads();
     {
-        const int x0 = wave_min(valid ? L : INT_MAX), y0 = wave_min(valid ? T : INT_MAX);
-        const int x1 = wave_max(valid ? L + 3 : INT_MIN), y1 = wave_max(valid ? T + 3 : INT_MIN);
+        const int x0 = wave_min(bx_lo), y0w = wave_min(by_lo);
+        const int x1 = wave_max(bx_hi), y1 = wave_max(by_hi);
         if ((tid & 63) == 0 && x0 != INT_MAX) {
-            atomicMin(&box[0], x0); atomicMin(&box[1], y0);
+            atomicMin(&box[0], x0); atomicMin(&box[1], y0w);
             atomicMax(&box[2], x1); atomicMax(&box[3], y1);
         }
     }
@@ -104,80 +239,53 @@ __global__ __launch_bounds__(FI_THREADS) void fi_forward_ori_lds(
     const int bh = any_valid ? box[3] - by0 + 1 : 0;
     const int n = bw * bh;                                  // <= (w+2)*(h+2): fits int for any real frame
 
-    // ---- the 16 filter taps of this pixel
-    float f[16];
-    if (valid) {
-        const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    // ---- the 16 filter taps of each pixel
 #pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = fpx[(int64_t)k * s3.c];
-    } else {
+    for (int p = 0; p < FI_PX; ++p) {
+        px[p].lbase = (T[p] - by0) * bw + (L[p] - bx0);
+        if (px[p].valid) {
+            const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)(y0 + p * FI_PASS_ROWS) * s3.h + x;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = 0.0f;
+            for (int k = 0; k < 16; ++k) px[p].f[k] = fpx[(int64_t)k * s3.c];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) px[p].f[k] = 0.0f;
+        }
     }
 
     const float* img = in1 + (int64_t)b * s1.b;
-    const int64_t pix = (int64_t)y * s1.h + x;
-    float* dst = out + (int64_t)b * s1.b + pix;
+    float* dst = out + (int64_t)b * s1.b;
 
-    if (n > FI_CAP) {
+    const int kmax = (n + FI_THREADS - 1) / FI_THREADS;     // workgroup-uniform
+    if (kmax > FI_KTOP) {
         // window too large for LDS: gather from global memory (workgroup-uniform branch)
-        if (valid) {
-            fi4_channels_direct(img, dst, c_begin, c_end, s1.c, (int)s1.h, h, w, L, T, f, alpha, beta);
-        } else if (inimg) {
-            for (int c = c_begin; c < c_end; ++c) dst[(int64_t)c * s1.c] = img[(int64_t)c * s1.c + pix];
+#pragma unroll
+        for (int p = 0; p < FI_PX; ++p) {
+            if (px[p].valid) {
+                fi4_channels_direct(img, dst + px[p].pix, c_begin, c_end, s1.c, (int)s1.h, h, w, L[p], T[p], px[p].f,
+                                    px[p].alpha, px[p].beta);
+            } else if (px[p].inimg) {
+                for (int c = c_begin; c < c_end; ++c) dst[(int64_t)c * s1.c + px[p].pix] = img[(int64_t)c * s1.c + px[p].pix];
+            }
         }
         return;
     }
 
-    // ---- staging plan: element e = tid + k*1024 of the window, row-major with row length bw
-    int goff[FI_NPT];
-#pragma unroll
-    for (int k = 0; k < FI_NPT; ++k) {
-        const int e = tid + k * FI_THREADS;
-        const int r = (bw > 0) ? e / bw : 0;
-        const int col = e - r * bw;
-        goff[k] = clampi(by0 + r, 0, h - 1) * (int)s1.h + clampi(bx0 + col, 0, w - 1);
-    }
-    const int kmax = (n + FI_THREADS - 1) / FI_THREADS;     // workgroup-uniform trip count
-    // LDS address of this pixel's window origin; rows are bw floats apart
-    const int lbase = (T - by0) * bw + (L - bx0);
-
-    float stage[FI_NPT];
-    auto load_window = [&](int c) {
-        const float* p = img + (int64_t)c * s1.c;
-#pragma unroll
-        for (int k = 0; k < FI_NPT; ++k)
-            if (k < kmax && tid + k * FI_THREADS < n) stage[k] = p[goff[k]];
-    };
-    auto store_window = [&](int which) {
-#pragma unroll
-        for (int k = 0; k < FI_NPT; ++k)
-            if (k < kmax && tid + k * FI_THREADS < n) buf[which][tid + k * FI_THREADS] = stage[k];
-    };
-
-    if (c_begin < c_end) {
-        load_window(c_begin);
-        store_window(0);
-        if (c_begin + 1 < c_end) load_window(c_begin + 1);
-    }
-    __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        if (valid) {
-            const float* t = &buf[cur][lbase];
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * bw + k];
-            dst[(int64_t)c * s1.c] = fi4_pixel(v, f, alpha, beta);
-        } else if (inimg) {
-            dst[(int64_t)c * s1.c] = img[(int64_t)c * s1.c + pix];     // copy-through (:2814-2818)
-        }
-        if (c + 1 < c_end) store_window(cur ^ 1);
-        if (c + 2 < c_end) load_window(c + 2);
-        __syncthreads();
-    }
+    const FiWindow win{bx0, by0, bw, n, h, w, (int)s1.h};
+    float* ring = lds + FI_HDR;
+#define FI_RUN(K) fi_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
+                                     min(FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)))
+    if (kmax <= 2) FI_RUN(2);
+    else if (kmax == 3) FI_RUN(3);
+    else if (kmax == 4) FI_RUN(4);
+    else if (kmax == 5) FI_RUN(5);
+    else if (kmax == 6) FI_RUN(6);
+    else if (kmax == 7) FI_RUN(7);
+    else if (kmax == 8) FI_RUN(8);
+    else if (kmax <= 10) FI_RUN(10);
+    else if (kmax <= 12) FI_RUN(12);
+    else FI_RUN(15);
+#undef FI_RUN
 }
 
 }  // namespace vfi
@@ -202,17 +310,17 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
                                                  float* output, int batch, int channel, int h, int w,
                                                  vfi_strides s1, vfi_strides s2, vfi_strides s3,
                                                  vfi_stream_t stream) {
-    // plane offsets inside the kernel are 32-bit
-    if ((int64_t)h * s1.h > INT_MAX) return -1;
+    // byte offsets inside a plane are 32-bit in the kernel
+    if ((int64_t)h * s1.h * 4 > INT_MAX) return -1;
     const int tiles_x = (w + FI_TW - 1) / FI_TW, tiles_y = (h + FI_TH - 1) / FI_TH;
     const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
     if (nt > (1 << 28)) return -1;
     const int ntiles = (int)nt;
     const int per_xcd = (ntiles + FI_XCDS - 1) / FI_XCDS;
 
-    // split the channel range over blockIdx.y when that shortens the tail: two
-    // 1024-thread workgroups per CU run at a time; every extra group re-reads the
-    // flow + 16 filter planes (72 B/pixel) next to 8 B/pixel/channel of image traffic
+    // split the channel range over blockIdx.y when that shortens the tail: two workgroups per
+    // CU run at a time; every extra group re-reads the flow + 16 filter planes (72 B/pixel)
+    // next to 8 B/pixel/channel of image traffic
     const int slots = fi_cu_count() * 2;
     int best_groups = 1;
     double best_cost = 0.0;
