@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--knobs", default="", help="comma list of flags:groups pairs for vfi_debug_filterinterp, e.g. 0:0,1:0,0:1")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     h, w = S.padded_size(args.height, args.width)
@@ -49,6 +50,14 @@ def main():
     ops = args.ops.split(",")
     for model in args.flows.split(","):
         flow = S.flow(1, h, w, 8.0 * w / 1984.0, gen, model).to(dev)
+        for knob in [k for k in args.knobs.split(",") if k]:
+            fl, gr = (int(v, 0) for v in knob.split(":"))
+            cabi.lib().vfi_debug_filterinterp(fl, gr)
+            ms = timed(lambda: cabi.filterinterp_forward_ori(ctx, flow, filt, out196), args.iters)
+            ms3 = timed(lambda: cabi.filterinterp_forward_ori(frame, flow, filt, out3), args.iters * 5)
+            print("knob flags=%#x groups=%d %-8s fi196 %8.4f ms %7.1f GB/s | fi3 %8.4f ms %7.1f GB/s"
+                  % (fl, gr, model, ms, 1640.0 * px / ms / 1e6, ms3, 96.0 * px / ms3 / 1e6), flush=True)
+            cabi.lib().vfi_debug_filterinterp(0, 0)
         for direct in (False, True):
             tag = "direct" if direct else "lds"
             if "fi196" in ops:

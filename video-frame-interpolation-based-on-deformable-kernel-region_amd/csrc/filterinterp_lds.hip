@@ -27,10 +27,10 @@
 // A tile whose tap window does not fit the LDS budget (wildly divergent flow)
 // gathers from global memory instead -- same results, decided per workgroup.
 //
-// Launch: 1-D grid; block b -> tile so that the blocks of one XCD (b % 8) own a
-// contiguous band of tiles: neighbouring tiles re-read each other's halo rows
-// from the same L2.  An optional split of the channel range over blockIdx.y
-// shortens the tail when the tile count does not fill the chip evenly.
+// Launch: 1-D grid of tiles in row-major order (an XCD-contiguous band mapping
+// was measured slower, see the kernel).  An optional split of the channel range
+// over blockIdx.y shortens the tail when the tile count does not fill the chip
+// evenly.
 #include "filterinterp_dev.h"
 
 #include <limits.h>
@@ -73,7 +73,7 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-struct FiWindow { int bx0, by0, bw, n, h, w, hs; };
+struct FiWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
 struct FiPixel {
     bool valid, inimg;
     float alpha, beta;
@@ -99,23 +99,27 @@ __device__ __forceinline__ void fi_wait_windows(int younger_groups) {
 template <int K>
 __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
                                                 int c_begin, int c_end, int tid, const FiWindow& win,
-                                                const FiPixel (&px)[FI_PX], float* __restrict__ ring, int R) {
+                                                const FiPixel (&px)[FI_PX], float* __restrict__ ring, int R,
+                                                int flags) {
     static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
-    // element e = tid + k*FI_THREADS of the window, row-major with row length bw.  Elements past
-    // the window (e >= n) re-read element 0 and land in the slot's slack, so the DMA loads are
-    // unconditional straight-line code.  Addressing is buffer-style: a wave-uniform descriptor of
-    // the channel's plane (rebuilt per channel from scalars) + one 32-bit byte offset per element
-    // that never changes -- no per-channel vector address arithmetic, one VGPR per element.  One
-    // buffer_load_dword ... lds writes 64 consecutive floats: LDS destination = wave-uniform base
-    // + lane*4, which is exactly this flat layout.
+    // Element e = tid + k*FI_THREADS of the staged window, row-major with row pitch `pitch` = bw
+    // rounded up to a multiple of 32 floats: with the pitch a multiple of the 32 LDS banks a tap's
+    // bank depends on its column only, so lanes of a wave whose windows sit on different rows do
+    // not collide (measured with the compact pitch bw: 58 % of the LDS cycles were conflicts).
+    // Pad columns and elements past the last row get an out-of-range buffer offset: the load
+    // returns 0 without touching memory, so the DMA loads are unconditional straight-line code.
+    // Addressing is buffer-style: a wave-uniform descriptor of the channel's plane (rebuilt per
+    // channel from scalars) + one 32-bit byte offset per element that never changes -- no
+    // per-channel vector address arithmetic, one VGPR per element.  One buffer_load_dword ... lds
+    // writes 64 consecutive floats: LDS destination = wave-uniform base + lane*4 = this layout.
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        int e = tid + k * FI_THREADS;
-        e = (e < win.n) ? e : 0;
-        const int r = (win.bw > 0) ? e / win.bw : 0;
-        const int col = e - r * win.bw;
-        goff[k] = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+        const int e = tid + k * FI_THREADS;
+        const int r = e / win.pitch;
+        const int col = e - r * win.pitch;
+        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+        goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
     }
     const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
     constexpr int NP = K * FI_THREADS;                      // floats per ring slot
@@ -138,7 +142,7 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.bw + k];
+                    for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.pitch + k];
                 o[px[p].pix] = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
             }
         }
@@ -152,9 +156,11 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
     __builtin_amdgcn_s_barrier();                                   // ... in every wave
     int slot = 0;
     for (int c = c_begin; c <= last; ++c) {
-        compute(c, slot);
         // the slot read in the previous iteration is free: every wave passed that barrier
-        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
+        // (issuing before the compute phase measured ~5 % faster than after it: flag bit 0)
+        if (!(flags & 1) && c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
+        compute(c, slot);
+        if ((flags & 1) && c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
         if (c < last) fi_wait_windows<K>(min(c + D, last) - (c + 1));
         __builtin_amdgcn_s_barrier();
         slot = (slot + 1 == R) ? 0 : slot + 1;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3,
-    int tiles_x, int tiles_y, int ntiles, int per_xcd, int ch_per_group) {
+    int tiles_x, int tiles_y, int ntiles, int per_xcd, int ch_per_group, int flags) {
     // ONE LDS array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt
     // before LDS reads): 16-float header holding the bounding box, then the window ring
     __shared__ float lds[FI_HDR + FI_RING_FLOATS];
@@ -180,7 +186,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
     // ---- block -> tile (XCD-contiguous bands)
     const int bid = blockIdx.x;
-    const int tile = (bid % FI_XCDS) * per_xcd + bid / FI_XCDS;
+    // Measured (1080p, C=196): the plain order, consecutive tiles dealt round-robin over the XCDs,
+    // is ~12 % faster than giving every XCD a contiguous band of tiles, so that is the default;
+    // flag bit 1 selects the band mapping for experiments.
+    const int tile = (flags & 2) ? (bid % FI_XCDS) * per_xcd + bid / FI_XCDS : bid;
     if (tile >= ntiles) return;                             // whole workgroup leaves together
     const int b = tile / (tiles_x * tiles_y);
     const int trem = tile - b * (tiles_x * tiles_y);
@@ -237,12 +246,13 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const bool any_valid = bx0 != INT_MAX;
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
     const int bh = any_valid ? box[3] - by0 + 1 : 0;
-    const int n = bw * bh;                                  // <= (w+2)*(h+2): fits int for any real frame
+    const int pitch = (bw + 31) & ~31;                      // LDS row pitch: a multiple of the 32 banks
+    const int n = pitch * bh;                               // <= (w+33)*(h+2): fits int for any real frame
 
     // ---- the 16 filter taps of each pixel
 #pragma unroll
     for (int p = 0; p < FI_PX; ++p) {
-        px[p].lbase = (T[p] - by0) * bw + (L[p] - bx0);
+        px[p].lbase = (T[p] - by0) * pitch + (L[p] - bx0);
         if (px[p].valid) {
             const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)(y0 + p * FI_PASS_ROWS) * s3.h + x;
 #pragma unroll
@@ -271,10 +281,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
         return;
     }
 
-    const FiWindow win{bx0, by0, bw, n, h, w, (int)s1.h};
+    const FiWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FI_HDR;
 #define FI_RUN(K) fi_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
-                                     min(FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)))
+                                     min((flags >> 8) ? (flags >> 8) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags)
     if (kmax <= 2) FI_RUN(2);
     else if (kmax == 3) FI_RUN(3);
     else if (kmax == 4) FI_RUN(4);
@@ -291,6 +301,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 }  // namespace vfi
 
 using namespace vfi;
+
+// development knobs (tools/bench_ops.py --knob): 0 = defaults
+static int g_fi_flags = 0, g_fi_groups = 0;
+extern "C" void vfi_debug_filterinterp(int flags, int groups) { g_fi_flags = flags; g_fi_groups = groups; }
 
 static int fi_cu_count() {
     static int cus = 0;
@@ -331,11 +345,12 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
         const double cost = tail * bytes;
         if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
     }
+    if (g_fi_groups > 0) best_groups = g_fi_groups < channel ? g_fi_groups : channel;
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
 
     const dim3 grid((unsigned)(per_xcd * FI_XCDS), (unsigned)groups, 1);
     hipLaunchKernelGGL(fi_forward_ori_lds, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
-                       input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group);
+                       input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags);
     return launch_status();
 }
