@@ -228,6 +228,35 @@ def test_projection_edge_cases(torch_mod, cabi, oracle):
             assert np.array_equal(cpu(out), ref) and np.array_equal(cpu(count), rcount)
 
 
+def test_projection_fallback_and_workspace_reuse(torch_mod, cabi, oracle):
+    """Fields whose sources reach many tiles overflow the per-tile lists and take the atomic
+    fallback; normal and fallback calls alternate on one stream and frame sizes change (the
+    workspace is per stream, grown on demand, and its lists must be empty again after each call)."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    for (B, H, W, kind) in ((1, 64, 200, "smooth"), (2, 96, 520, "wild"), (2, 96, 520, "smooth"), (1, 40, 130, "wild"),
+                            (1, 200, 700, "smooth"), (1, 64, 200, "rows")):
+        if kind == "smooth":
+            flow = smooth_flow(rng, B, H, W, 3.0)
+        elif kind == "wild":
+            flow = rng.uniform(-W / 2, W / 2, (B, 2, H, W)).astype(f32)
+        else:       # every source lands in one row of the frame: a few tiles collect everything
+            flow = np.zeros((B, 2, H, W), f32)
+            flow[:, 1] = 5.0 - np.arange(H)[None, :, None]
+        fq = (np.round(flow * 8) / 8).astype(f32)
+        depth = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
+        for fh in (1, 0):
+            count = torch.zeros((B, 1, H, W), device="cuda:0")
+            out = torch.zeros((B, 2, H, W), device="cuda:0")
+            assert cabi.flowprojection_forward(gpu(torch, fq), count, out, fh) == 0
+            ref, rcount = oracle.flowproj_fwd(fq, fh)
+            assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref), (B, H, W, kind, fh)
+            count.zero_(), out.zero_()
+            assert cabi.depthflowprojection_forward(gpu(torch, fq), gpu(torch, depth), count, out, fh) == 0
+            ref, rcount = oracle.depthflowproj_fwd(fq, depth, fh)
+            assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref), (B, H, W, kind, fh)
+
+
 def test_projection_backward(torch_mod, cabi, oracle):
     torch = torch_mod
     rng = np.random.default_rng(21)

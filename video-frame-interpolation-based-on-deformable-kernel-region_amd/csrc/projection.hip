@@ -5,93 +5,430 @@
 // depthflowprojection_cuda_kernel.cu:29-341 of the reference; entry points
 // replace flowprojection_cuda.cc / depthflowprojection_cuda.cc.
 //
-// Forward = three passes on one stream, as in the reference (the hole filler
-// needs the complete count plane):
+// What is computed (three steps in the reference, each its own launch there):
 //   1. splat: every source pixel adds (-d*fx, -d*fy, d) to its 4 integer
-//      neighbours (d = 1 without depth);
+//      neighbours (d = 1 without depth) -- 12 global atomics per pixel there;
 //   2. normalise where count > 0;
-//   3. optional hole fill from the nearest non-hole in -x, +x, -y, +y.
+//   3. optional hole fill from the nearest non-hole in -x, +x, -y, +y (needs the
+//      complete count plane, so it stays a separate launch).
+//
+// How (owner computes; no global atomics on the normal path): the frame is cut
+// into 64x16 tiles, used both as source tiles and as output tiles.
+//   A  proj_bin     one wave per SOURCE row segment (64 pixels of one row): bounding
+//                   box of the segment's targets -> the segment appends its id to
+//                   the list of every OUTPUT tile that box touches (~2 MB of lists
+//                   in a workspace; lists hold PROJ_LIST_CAP entries).
+//   B  proj_gather  one workgroup per OUTPUT tile: accumulates the three planes of
+//                   its tile in LDS from the row segments on its list (one wave per
+//                   segment), then writes count and the normalised flow once,
+//                   coalesced.
+//   C  proj_average only does work on the fallback path.
+//   D  proj_fillhole
+// Fallback: when any list overflows (fields with displacements of many tiles,
+// e.g. random flow of +-W/2), B instead splats its own source tile with global
+// atomics exactly like the reference, and C normalises.  The switch is a serial
+// number in the workspace written by A and read by B and C: no host round trip.
+//
+// Accumulation in B is 64-bit fixed point (ds_add_u64): on gfx950 an LDS float atomic add
+// costs ~170 cycles per wave instruction (measured, tools/probes/lds_atomic_probe.hip), an
+// integer one ~6.  Every addend is scaled by a power of two chosen per call from the
+// largest |addend| (found by A) so that no cell can overflow, rounded to an integer and
+// summed exactly; the integer sum is converted back to float once.  The result is the
+// correctly rounded sum (the reference's fp32 atomic sum carries one rounding per addend,
+// in arrival order), independent of summation order and therefore reproducible bit for bit
+// from run to run.  It agrees with any fp32 summation order to rounding; addends that are
+// multiples of 2^-k (k < ~30) sum exactly in both.  count of FlowProjection is exact.
 #include "vfi_common.h"
+
+#include <limits.h>
+
+#include <mutex>
+#include <vector>
 
 namespace vfi {
 
+#define PROJ_TW 64
+#define PROJ_TH 16
+#define PROJ_THREADS 256
+#define PROJ_LIST_CAP 252           // source row segments per output tile before the fallback kicks in
+
+// workspace "words" (32-bit): [0] serial of the last call whose lists overflowed; from word 16 one
+// record per output tile: [0] list length, [1] / [2] bit patterns of the largest |value addend| /
+// count addend among the listed segments (atomicMax by A), [3] unused, then PROJ_LIST_CAP segment
+// ids.  B resets words 0..2 after reading them, so a record is empty between calls.
+// workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and
+// one packed along columns (colmap[b][x][y/32]), written by B for the hole filler (A clears the
+// column-packed one, whose words are shared by two tiles); its own allocation, so its layout
+// (which depends on the frame size) cannot disturb the records.  A record's position depends on the tile index only, so calls with different frame
+// sizes can share the workspace without stale lengths.
+#define PROJ_WS_HDR 16
+#define PROJ_WS_REC (4 + PROJ_LIST_CAP)
+#define PROJ_REC_VMAX 1
+#define PROJ_REC_CMAX 2
+#define PROJ_REC_IDS 4
+static inline size_t proj_ws_tile_words(int ntiles) { return PROJ_WS_HDR + (size_t)ntiles * PROJ_WS_REC; }
+
+// rmw / cmw: 32-bit words per image row / column of the two "count != 0" bitmaps;
+// rowmap / colmap: their word offsets inside the workspace's bit buffer
+struct ProjGeom { int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap; };
+
+// one source pixel: validity, the four target cells (in order TL, TR, BL, BR) and the three addends
+struct ProjSplat {
+    bool valid;
+    int L, T, R, Bm;
+    float ax, ay, ac;
+};
+
 template <bool DEPTH>
-__global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_splat(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* count, float* out,
-    int h, int w, vfi_strides s1, vfi_strides s2, vfi_strides sc) {
-    const int x = blockIdx.x * VFI_TX + threadIdx.x;
-    const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const int b = blockIdx.z;
+__device__ __forceinline__ ProjSplat proj_source(const float* __restrict__ in1, const float* __restrict__ in2,
+                                                 int b, int x, int y, int h, int w, vfi_strides s1, vfi_strides s2) {
+    ProjSplat s;
+    s.valid = false;
+    s.L = s.T = s.R = s.Bm = 0;
+    s.ax = s.ay = s.ac = 0.0f;
+    if (x >= w || y >= h) return s;
     const float* flow = in1 + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
     const float fx = flow[0];
     const float fy = flow[s1.c];
     const float x2 = (float)x + fx;
     const float y2 = (float)y + fy;
-    if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1))) return;
-    const int L = (int)x2, T = (int)y2;
-    const int R = min(L + 1, w - 1), Bm = min(T + 1, h - 1);
-    float ax = -fx, ay = -fy, ac = 1.0f;
+    if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1))) return s;
+    s.valid = true;
+    s.L = (int)x2;
+    s.T = (int)y2;
+    s.R = min(s.L + 1, w - 1);
+    s.Bm = min(s.T + 1, h - 1);
     if constexpr (DEPTH) {
         const float d = in2[(int64_t)b * s2.b + (int64_t)y * s2.h + x];
-        ax = -d * fx; ay = -d * fy; ac = d;
+        s.ax = -d * fx; s.ay = -d * fy; s.ac = d;       // depthflowprojection_cuda_kernel.cu:74-91
+    } else {
+        s.ax = -fx; s.ay = -fy; s.ac = 1.0f;            // flowprojection_cuda_kernel.cu:75-88
     }
-    float* o0 = out + (int64_t)b * s1.b;
-    float* o1 = o0 + s1.c;
-    float* cn = count + (int64_t)b * sc.b;
-    const int64_t oT = (int64_t)T * s1.h, oB = (int64_t)Bm * s1.h;
-    const int64_t cT = (int64_t)T * sc.h, cB = (int64_t)Bm * sc.h;
-    // R == L / Bm == T at the far edges: the same cell receives the value twice (:72-73)
-    atomicAdd(&o0[oT + L], ax); atomicAdd(&o0[oT + R], ax); atomicAdd(&o0[oB + L], ax); atomicAdd(&o0[oB + R], ax);
-    atomicAdd(&o1[oT + L], ay); atomicAdd(&o1[oT + R], ay); atomicAdd(&o1[oB + L], ay); atomicAdd(&o1[oB + R], ay);
-    atomicAdd(&cn[cT + L], ac); atomicAdd(&cn[cT + R], ac); atomicAdd(&cn[cB + L], ac); atomicAdd(&cn[cB + R], ac);
+    return s;
 }
 
-__global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_average(
-    const float* __restrict__ count, float* out, int h, int w, vfi_strides s1, vfi_strides sc) {
-    const int x = blockIdx.x * VFI_TX + threadIdx.x;
-    const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const int b = blockIdx.z;
-    const float c = count[(int64_t)b * sc.b + (int64_t)y * sc.h + x];
-    if (c > 0.0f) {
-        float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-        o[0] /= c;
-        o[s1.c] /= c;
+__device__ __forceinline__ int wmin(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wmax(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// A: bin source row segments into the lists of the output tiles they reach.  A workgroup covers the
+// 64x16 tile of its index: its 16 row segments first find their target rectangles (in tiles), then
+// one thread per candidate output tile reserves, with ONE returning atomic, room for all the
+// segments that reach that tile and writes their ids (a returning atomic per segment and tile
+// measured 4x slower: the round trips serialise).
+#define PROJ_BIN_CAND 64            // candidate output tiles per source tile handled by the fast path
+template <bool DEPTH>
+__global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
+    const float* __restrict__ in1, const float* __restrict__ in2, ProjGeom g, vfi_strides s1, vfi_strides s2,
+    int* __restrict__ ws, int* __restrict__ bits, int serial) {
+    __shared__ int rect[PROJ_TH][4];                        // per row segment: tx0, ty0, tx1, ty1 (tx0 < 0: none)
+    __shared__ int tmax[2];
+    const int tile = blockIdx.x;
+    const int b = tile / (g.tiles_x * g.tiles_y);
+    const int trem = tile - b * (g.tiles_x * g.tiles_y);
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = txi * PROJ_TW + lane;
+    // clear the column-packed bitmap words this tile shares with the tile below it (32 rows per word)
+    if ((tyi & 1) == 0 && tid < PROJ_TW && x < g.w) bits[g.colmap + (b * g.w + x) * g.cmw + (tyi >> 1)] = 0;
+    if (tid < 2) tmax[tid] = 0;
+    __syncthreads();
+    ProjSplat s[PROJ_TH / 4];
+#pragma unroll
+    for (int r = 0; r < PROJ_TH / 4; ++r)                   // all loads first
+        s[r] = proj_source<DEPTH>(in1, in2, b, x, tyi * PROJ_TH + wave + r * 4, g.h, g.w, s1, s2);
+    int vbits = 0, cbits = 0;
+#pragma unroll
+    for (int r = 0; r < PROJ_TH / 4; ++r) {
+        const int x0 = wmin(s[r].valid ? s[r].L : INT_MAX), x1 = wmax(s[r].valid ? s[r].R : INT_MIN);
+        const int y0 = wmin(s[r].valid ? s[r].T : INT_MAX), y1 = wmax(s[r].valid ? s[r].Bm : INT_MIN);
+        // non-negative floats order like their bit patterns
+        vbits = max(vbits, __float_as_int(s[r].valid ? fmaxf(fabsf(s[r].ax), fabsf(s[r].ay)) : 0.0f));
+        cbits = max(cbits, __float_as_int(s[r].valid ? fabsf(s[r].ac) : 0.0f));
+        if (lane == 0) {
+            int* q = rect[wave + r * 4];
+            const bool any = x0 != INT_MAX;
+            q[0] = any ? x0 / PROJ_TW : -1; q[1] = any ? y0 / PROJ_TH : 0;
+            q[2] = any ? x1 / PROJ_TW : -1; q[3] = any ? y1 / PROJ_TH : 0;
+        }
+    }
+    vbits = wmax(vbits); cbits = wmax(cbits);
+    if (lane == 0) { atomicMax(&tmax[0], vbits); atomicMax(&tmax[1], cbits); }
+    __syncthreads();
+    // union rectangle of the tile's segments
+    int cx0 = INT_MAX, cy0 = INT_MAX, cx1 = INT_MIN, cy1 = INT_MIN;
+#pragma unroll
+    for (int r = 0; r < PROJ_TH; ++r)
+        if (rect[r][0] >= 0) {
+            cx0 = min(cx0, rect[r][0]); cy0 = min(cy0, rect[r][1]);
+            cx1 = max(cx1, rect[r][2]); cy1 = max(cy1, rect[r][3]);
+        }
+    if (cx0 == INT_MAX) return;                             // nothing of this tile lands in the frame
+    const int nx = cx1 - cx0 + 1, ncand = nx * (cy1 - cy0 + 1);
+    const int vmax = tmax[0], cmax = tmax[1];
+    const int seg0 = (b * g.h + tyi * PROJ_TH) * g.tiles_x + txi;
+    for (int c = tid; c < ncand; c += PROJ_THREADS) {
+        const int ctx = cx0 + c % nx, cty = cy0 + c / nx;
+        unsigned rows = 0u;                                 // which of the 16 segments reach this output tile
+#pragma unroll
+        for (int r = 0; r < PROJ_TH; ++r)
+            if (rect[r][0] >= 0 && ctx >= rect[r][0] && ctx <= rect[r][2] && cty >= rect[r][1] && cty <= rect[r][3])
+                rows |= 1u << r;
+        if (!rows) continue;
+        int* rec = ws + PROJ_WS_HDR + (int64_t)((b * g.tiles_y + cty) * g.tiles_x + ctx) * PROJ_WS_REC;
+        int slot = atomicAdd(&rec[0], __popc(rows));
+        if (slot + __popc(rows) > PROJ_LIST_CAP) { ws[0] = serial; continue; }    // overflow: fallback path
+        while (rows) {
+            const int r = __ffs((int)rows) - 1;
+            rows &= rows - 1u;
+            rec[PROJ_REC_IDS + slot++] = seg0 + r * g.tiles_x;
+        }
+        if (vmax > __hip_atomic_load(&rec[PROJ_REC_VMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&rec[PROJ_REC_VMAX], vmax);
+        if (cmax > __hip_atomic_load(&rec[PROJ_REC_CMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&rec[PROJ_REC_CMAX], cmax);
     }
 }
 
-// pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a
-// non-hole (never written by this pass) or is multiplied by 0.
+// B: one workgroup per output tile
+template <bool DEPTH>
+__global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
+    ProjGeom g, vfi_strides s1, vfi_strides s2, vfi_strides sc, int* __restrict__ ws, int* __restrict__ bits,
+    int serial) {
+    __shared__ unsigned long long acc[3][PROJ_TH][PROJ_TW];
+    const int tile = blockIdx.x;
+    const int b = tile / (g.tiles_x * g.tiles_y);
+    const int trem = tile - b * (g.tiles_x * g.tiles_y);
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int* rec = ws + PROJ_WS_HDR + (int64_t)tile * PROJ_WS_REC;
+    const int* list = rec + PROJ_REC_IDS;
+    const int nsrc = min(rec[0], PROJ_LIST_CAP);
+    const int vb = rec[PROJ_REC_VMAX], cb = rec[PROJ_REC_CMAX];
+    const bool fallback = ws[0] == serial;
+    // fixed-point scales: addend * 2^k rounded to int64.  A cell of this tile receives at most
+    // 4 * h * w addends (nb bits), all from the segments on this tile's list, each below 2^e with e
+    // from the list's maxima: k = 62 - nb - e keeps every sum inside int64.  (Per output tile, so no
+    // global reduction is needed; a sum only ever mixes addends of one scale.)
+    const int nb = 34 - __clz((unsigned)max(1, (int)min((int64_t)INT_MAX, (int64_t)g.h * g.w)));   // >= log2(4*h*w)
+    int ev = 0, ec = 0;
+    (void)frexpf(__int_as_float(vb), &ev);
+    (void)frexpf(__int_as_float(cb), &ec);
+    // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
+    const int kv = max(-100, min(100, 62 - nb - ev)), kc = max(-100, min(100, 62 - nb - ec));
+    const float sv = ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);     // exact powers of two
+    __syncthreads();                                        // every thread has read the record ...
+    if (tid < 3) rec[tid] = 0;                              // ... leave it empty for the next call
+
+    if (fallback) {
+        // the reference's own scheme: this tile as SOURCE tile, global atomics into the zero-filled planes
+        float* o0 = out + (int64_t)b * s1.b;
+        float* o1 = o0 + s1.c;
+        float* cn = count + (int64_t)b * sc.b;
+#pragma unroll
+        for (int r = 0; r < PROJ_TH / 4; ++r) {
+            const ProjSplat s = proj_source<DEPTH>(in1, in2, b, txi * PROJ_TW + lane, tyi * PROJ_TH + wave + r * 4,
+                                                   g.h, g.w, s1, s2);
+            if (!s.valid) continue;
+            const int64_t oT = (int64_t)s.T * s1.h, oB = (int64_t)s.Bm * s1.h;
+            const int64_t cT = (int64_t)s.T * sc.h, cB = (int64_t)s.Bm * sc.h;
+            atomicAdd(&o0[oT + s.L], s.ax); atomicAdd(&o0[oT + s.R], s.ax); atomicAdd(&o0[oB + s.L], s.ax); atomicAdd(&o0[oB + s.R], s.ax);
+            atomicAdd(&o1[oT + s.L], s.ay); atomicAdd(&o1[oT + s.R], s.ay); atomicAdd(&o1[oB + s.L], s.ay); atomicAdd(&o1[oB + s.R], s.ay);
+            atomicAdd(&cn[cT + s.L], s.ac); atomicAdd(&cn[cT + s.R], s.ac); atomicAdd(&cn[cB + s.L], s.ac); atomicAdd(&cn[cB + s.R], s.ac);
+        }
+        return;
+    }
+
+    for (int i = tid; i < 3 * PROJ_TH * PROJ_TW; i += PROJ_THREADS) (&acc[0][0][0])[i] = 0ull;
+    __syncthreads();
+    const int ox0 = txi * PROJ_TW, oy0 = tyi * PROJ_TH;
+    // One wave per source row segment.  A wave first fetches all its list entries with one load
+    // (entry j of the wave sits in lane j), then walks them with the NEXT segment's pixels already in
+    // flight: no dependent list -> pixel load chain per segment.
+    const int mine = (nsrc > wave) ? (nsrc - wave + PROJ_THREADS / 64 - 1) / (PROJ_THREADS / 64) : 0;   // <= 63
+    const int ids = (lane < mine) ? list[wave + lane * (PROJ_THREADS / 64)] : 0;
+    auto fetch = [&](int j) {
+        const int seg = __shfl(ids, j);
+        return proj_source<DEPTH>(in1, in2, b, (seg % g.tiles_x) * PROJ_TW + lane, seg / g.tiles_x - b * g.h,
+                                  g.h, g.w, s1, s2);
+    };
+    ProjSplat nxt = fetch(0);                               // lane 0 holds 0 when the wave has no entry: harmless
+    for (int j = 0; j < mine; ++j) {
+        const ProjSplat s = nxt;
+        if (j + 1 < mine) nxt = fetch(j + 1);
+        // cells of this output tile only; R == L / Bm == T at the far edges add twice (:72-73)
+        const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
+        const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
+        const bool inT = (unsigned)ty < PROJ_TH, inB = (unsigned)by < PROJ_TH;
+        // addend * 2^k is exact in float (power-of-two scale, |product| < 2^40); two's complement:
+        // adding the unsigned image of a negative int64 subtracts
+        const unsigned long long qx = (unsigned long long)__float2ll_rn(s.ax * sv);
+        const unsigned long long qy = (unsigned long long)__float2ll_rn(s.ay * sv);
+        const unsigned long long qc = (unsigned long long)__float2ll_rn(s.ac * scn);
+        if (inT && inL) { atomicAdd(&acc[0][ty][lx], qx); atomicAdd(&acc[1][ty][lx], qy); atomicAdd(&acc[2][ty][lx], qc); }
+        if (inT && inR) { atomicAdd(&acc[0][ty][rx], qx); atomicAdd(&acc[1][ty][rx], qy); atomicAdd(&acc[2][ty][rx], qc); }
+        if (inB && inL) { atomicAdd(&acc[0][by][lx], qx); atomicAdd(&acc[1][by][lx], qy); atomicAdd(&acc[2][by][lx], qc); }
+        if (inB && inR) { atomicAdd(&acc[0][by][rx], qx); atomicAdd(&acc[1][by][rx], qy); atomicAdd(&acc[2][by][rx], qc); }
+    }
+    __syncthreads();
+    // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once; leave the two
+    // "count != 0" bitmaps for the hole filler
+    __shared__ unsigned colm[PROJ_TW];
+    if (tid < PROJ_TW) colm[tid] = 0u;
+    __syncthreads();
+    const int x = ox0 + lane;
+    {
+        unsigned mine = 0u;
+#pragma unroll
+        for (int r = 0; r < PROJ_TH / 4; ++r) {
+            const int yl = wave + r * 4;
+            const bool nz = acc[2][yl][lane] != 0ull && x < g.w && oy0 + yl < g.h;
+            const unsigned long long rowbits = __ballot(nz);
+            if (lane < 2 && oy0 + yl < g.h && txi * 2 + lane < g.rmw)
+                bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
+            if (nz) mine |= 1u << yl;
+        }
+        if (mine) atomicOr(&colm[lane], mine);
+    }
+    __syncthreads();
+    if (tid < PROJ_TW && colm[tid] && ox0 + tid < g.w)
+        atomicOr(&bits[g.colmap + (b * g.w + ox0 + tid) * g.cmw + (tyi >> 1)], (int)(colm[tid] << ((tyi & 1) * 16)));
+    if (x < g.w) {
+#pragma unroll
+        for (int r = 0; r < PROJ_TH / 4; ++r) {
+            const int yl = wave + r * 4, y = oy0 + yl;
+            if (y >= g.h) continue;
+            // exact integer sums -> float once (through double: one rounding)
+            const float c = (float)ldexp((double)(long long)acc[2][yl][lane], -kc);
+            float vx = (float)ldexp((double)(long long)acc[0][yl][lane], -kv);
+            float vy = (float)ldexp((double)(long long)acc[1][yl][lane], -kv);
+            if (c > 0.0f) { vx /= c; vy /= c; }
+            float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+            o[0] = vx;
+            o[s1.c] = vy;
+            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
+        }
+    }
+}
+
+// C: pass 2 of the fallback path (otherwise 512 workgroups that return at once)
+__global__ __launch_bounds__(256) void proj_average(
+    const float* __restrict__ count, float* out, int batch, int h, int w, vfi_strides s1, vfi_strides sc,
+    const int* __restrict__ ws, int serial) {
+    if (ws[0] != serial) return;
+    const int64_t total = (int64_t)batch * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int b = (int)(i / ((int64_t)w * h));
+        const float c = count[(int64_t)b * sc.b + (int64_t)y * sc.h + x];
+        if (c > 0.0f) {
+            float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+            o[0] /= c;
+            o[s1.c] /= c;
+        }
+    }
+}
+
+// D: pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a non-hole
+// (never written by this pass) or is multiplied by 0.
+//
+// The reference walks cell by cell from every hole until it meets a non-zero count; along an
+// uncovered border strip that is a dependent chain of up to H (or W) loads per hole.  On the
+// normal path B has left row-packed and column-packed bitmaps of "count != 0", so a walk is a
+// few word loads and a count-leading/trailing-zeros; only the cell found is then read.  The cell
+// found -- hence the result -- is the same.
+struct ProjScan { int pos; float cnt; };
+
+// first set bit strictly beyond position p0 in direction dir (-1 / +1) of a bitmap line of `len`
+// bits (32 per word); -1 if none.  Words are fetched four at a time (independent loads).
+__device__ __forceinline__ int proj_bit_walk(const int* __restrict__ line, int p0, int len, int dir) {
+    const int nw = (len + 31) >> 5;
+    int wi = p0 >> 5;
+    unsigned word = (unsigned)line[wi];
+    if (dir < 0) {
+        word &= (1u << (p0 & 31)) - 1u;
+        if (word) return wi * 32 + 31 - __clz(word);
+        for (wi -= 1; wi >= 0; wi -= 4) {
+            unsigned q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = (wi - k >= 0) ? (unsigned)line[wi - k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q[k]) return (wi - k) * 32 + 31 - __clz(q[k]);
+        }
+    } else {
+        word &= ((p0 & 31) == 31) ? 0u : ~((2u << (p0 & 31)) - 1u);
+        if (word) return wi * 32 + __ffs((int)word) - 1;
+        for (wi += 1; wi < nw; wi += 4) {
+            unsigned q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = (wi + k < nw) ? (unsigned)line[wi + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q[k]) return (wi + k) * 32 + __ffs((int)q[k]) - 1;
+        }
+    }
+    return -1;
+}
+
+// cell-by-cell walk of the reference (fallback path: no bitmaps)
+__device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn, int64_t origin, int64_t stride,
+                                                    int p0, int len, int dir) {
+    ProjScan r{p0, 0.0f};
+    while (r.cnt == 0.0f && r.pos + dir >= 0 && r.pos + dir <= len - 1) { r.pos += dir; r.cnt = cn[origin + (int64_t)r.pos * stride]; }
+    return r;
+}
+
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_fillhole(
-    const float* __restrict__ count, float* out, int h, int w, vfi_strides s1, vfi_strides sc) {
+    const float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
+    const int* __restrict__ ws, const int* __restrict__ bits, int serial) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    if (x >= w || y >= h) return;
+    if (x >= g.w || y >= g.h) return;
     const int b = blockIdx.z;
     const float* cn = count + (int64_t)b * sc.b;
     if (!(cn[(int64_t)y * sc.h + x] <= 0.0f)) return;
-    int lo = x; float lt = 0.0f;
-    while (lt == 0.0f && lo - 1 >= 0) { lo -= 1; lt = cn[(int64_t)y * sc.h + lo]; }
-    int ro = x; float rt = 0.0f;
-    while (rt == 0.0f && ro + 1 <= w - 1) { ro += 1; rt = cn[(int64_t)y * sc.h + ro]; }
-    int uo = y; float ut = 0.0f;
-    while (ut == 0.0f && uo - 1 >= 0) { uo -= 1; ut = cn[(int64_t)uo * sc.h + x]; }
-    int dn = y; float dt = 0.0f;
-    while (dt == 0.0f && dn + 1 <= h - 1) { dn += 1; dt = cn[(int64_t)dn * sc.h + x]; }
-    if (lt + rt + ut + dt <= 0.0f) return;
-    lt = (lt > 0.0f) ? 1.0f : 0.0f;
-    rt = (rt > 0.0f) ? 1.0f : 0.0f;
-    ut = (ut > 0.0f) ? 1.0f : 0.0f;
-    dt = (dt > 0.0f) ? 1.0f : 0.0f;
+    ProjScan l, r, u, d;
+    if (ws[0] != serial) {                                  // B ran its normal path and left the bitmaps
+        const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
+        const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
+        const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
+        const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
+        // a walk that found nothing contributes weight 0; its position only has to be valid
+        l.pos = xl < 0 ? x : xl; r.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
+        l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
+        r.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
+        u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
+        d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
+    } else {
+        l = proj_walk_plain(cn, (int64_t)y * sc.h, 1, x, g.w, -1);
+        r = proj_walk_plain(cn, (int64_t)y * sc.h, 1, x, g.w, +1);
+        u = proj_walk_plain(cn, x, sc.h, y, g.h, -1);
+        d = proj_walk_plain(cn, x, sc.h, y, g.h, +1);
+    }
+    if (l.cnt + r.cnt + u.cnt + d.cnt <= 0.0f) return;
+    const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
+    const float rt = (r.cnt > 0.0f) ? 1.0f : 0.0f;
+    const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
+    const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
     const float den = lt + rt + ut + dt;
     float* o0 = out + (int64_t)b * s1.b;
     float* o1 = o0 + s1.c;
     const int64_t row = (int64_t)y * s1.h;
-    o0[row + x] = (lt * o0[row + lo] + rt * o0[row + ro] + ut * o0[(int64_t)uo * s1.h + x] +
-                   dt * o0[(int64_t)dn * s1.h + x]) / den;
-    o1[row + x] = (lt * o1[row + lo] + rt * o1[row + ro] + ut * o1[(int64_t)uo * s1.h + x] +
-                   dt * o1[(int64_t)dn * s1.h + x]) / den;
+    o0[row + x] = (lt * o0[row + l.pos] + rt * o0[row + r.pos] + ut * o0[(int64_t)u.pos * s1.h + x] +
+                   dt * o0[(int64_t)d.pos * s1.h + x]) / den;
+    o1[row + x] = (lt * o1[row + l.pos] + rt * o1[row + r.pos] + ut * o1[(int64_t)u.pos * s1.h + x] +
+                   dt * o1[(int64_t)d.pos * s1.h + x]) / den;
 }
 
 template <bool DEPTH>
@@ -143,16 +480,75 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_backward(
     }
 }
 
+// Per (device, stream) workspace for the tile lists, allocated on first use and grown on demand.
+// hipMalloc happens on the first call for a given stream / a larger frame only (do a warm-up call
+// before capturing into a graph); calls on one stream are ordered, so one workspace per stream is
+// enough and two streams never share one.
+struct ProjWorkspace { int device; hipStream_t stream; int* words; size_t capacity; int* bits; size_t bit_capacity; int serial; };
+static std::mutex g_ws_mutex;
+static std::vector<ProjWorkspace> g_ws;
+
+static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_words) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    ProjWorkspace* w = nullptr;
+    for (auto& e : g_ws)
+        if (e.device == dev && e.stream == st) w = &e;
+    if (!w) {
+        g_ws.push_back(ProjWorkspace{dev, st, nullptr, 0, nullptr, 0, 0});
+        w = &g_ws.back();
+    }
+    if (w->capacity < words) {
+        if (w->words) (void)hipFree(w->words);              // synchronises: no kernel still uses it
+        w->words = nullptr;
+        w->capacity = 0;
+        if (hipMalloc(&w->words, words * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(w->words, 0, words * sizeof(int)) != hipSuccess) return nullptr;
+        w->capacity = words;
+        w->serial = 0;
+    }
+    if (w->bit_capacity < bit_words) {
+        if (w->bits) (void)hipFree(w->bits);
+        w->bits = nullptr;
+        w->bit_capacity = 0;
+        if (hipMalloc(&w->bits, bit_words * sizeof(int)) != hipSuccess) return nullptr;
+        w->bit_capacity = bit_words;                        // A clears what a call uses
+    }
+    w->serial += 1;                                         // serial 0 never matches: the header starts at 0
+    return w;
+}
+
 template <bool DEPTH>
 static int project_forward(const float* in1, const float* in2, float* count, float* out, int batch, int h, int w,
                            int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
-    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
-    hipLaunchKernelGGL(proj_splat<DEPTH>, grid, block, 0, st, in1, in2, count, out, h, w, s1, s2, sc);
+    ProjGeom g;
+    g.h = h; g.w = w;
+    g.tiles_x = (w + PROJ_TW - 1) / PROJ_TW;
+    g.tiles_y = (h + PROJ_TH - 1) / PROJ_TH;
+    const int64_t nt = (int64_t)g.tiles_x * g.tiles_y * batch;
+    if (nt > (1 << 24)) return VFI_ERR_SHAPE;
+    g.ntiles = (int)nt;
+    g.rmw = (w + 31) / 32;
+    g.cmw = (g.tiles_y * PROJ_TH + 31) / 32;                // whole tiles: B ORs 16-bit halves
+    const size_t tile_words = proj_ws_tile_words(g.ntiles);
+    const size_t bit_words = (size_t)batch * ((size_t)h * g.rmw + (size_t)w * g.cmw);
+    if (bit_words > (size_t)INT_MAX) return VFI_ERR_SHAPE;
+    g.rowmap = 0;
+    g.colmap = batch * h * g.rmw;
+    ProjWorkspace* ws = proj_workspace(st, tile_words, bit_words);
+    if (!ws) return VFI_ERR_LAUNCH;
+    hipLaunchKernelGGL(proj_bin<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, g, s1, s2, ws->words,
+                       ws->bits, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL(proj_average, grid, block, 0, st, count, out, h, w, s1, sc);
+    hipLaunchKernelGGL(proj_gather<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, count, out, g, s1, s2,
+                       sc, ws->words, ws->bits, ws->serial);
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
+    hipLaunchKernelGGL(proj_average, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     if (fillhole) {
-        hipLaunchKernelGGL(proj_fillhole, grid, block, 0, st, count, out, h, w, s1, sc);
+        hipLaunchKernelGGL(proj_fillhole, grid, block, 0, st, count, out, g, s1, sc, ws->words, ws->bits, ws->serial);
         if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     }
     return VFI_OK;
