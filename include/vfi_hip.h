@@ -17,11 +17,12 @@
  *  - return value: 0 = success, 1 = shape/stride problem (the reference
  *    bindings' silent `return 1`), VFI_ERR_LAUNCH = a HIP launch failed (the
  *    reference bindings raise AT_ERROR("CUDA call failed") for it);
- *  - the my_package ops expect the CALLER to zero-fill outputs / counts / grads
- *    (FilterInterpolationLayer.py:34, FlowProjectionLayer.py:35-36); the
- *    forward kernels here write every output element, so forward outputs need
- *    no zero fill, but `count`/`output` of the projections and every grad*
- *    buffer of a backward MUST arrive zeroed exactly as in the reference.
+ *  - the reference's my_package ops expect the CALLER to zero-fill outputs /
+ *    counts / grads (FilterInterpolationLayer.py:34, FlowProjectionLayer.py:35-36).
+ *    Every FORWARD entry point here writes every element of its outputs
+ *    (`count` and `output` of the projections included), so forward outputs need
+ *    no zero fill; a zero-filled buffer is of course accepted.  Every grad*
+ *    buffer of a BACKWARD must arrive zeroed exactly as in the reference.
  */
 #ifndef VFI_HIP_H
 #define VFI_HIP_H
@@ -81,7 +82,10 @@ int vfi_filterinterp_forward_defor(int variant,
 
 /* ---- flowprojection_cuda -----------------------------------------------------
  * replaces FlowProjectionLayer_gpu_forward / _backward (flowprojection_cuda.cc:9-57, 59-114).
- * count [B,1,H,W] and output [B,2,H,W] must arrive zero-filled. */
+ * count [B,1,H,W] and output [B,2,H,W] are fully written (no zero fill needed).
+ * The forward keeps a small per-stream device workspace (tile lists, bitmaps) that it
+ * allocates on its first call for a stream and grows on demand: make one warm-up call
+ * before capturing calls into a HIP graph. */
 int vfi_flowprojection_forward(const float* input1, float* count, float* output,
                                int batch, int h, int w, int fillhole,
                                vfi_strides s1, vfi_strides sc,

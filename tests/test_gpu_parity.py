@@ -246,12 +246,13 @@ def test_projection_fallback_and_workspace_reuse(torch_mod, cabi, oracle):
         fq = (np.round(flow * 8) / 8).astype(f32)
         depth = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
         for fh in (1, 0):
-            count = torch.zeros((B, 1, H, W), device="cuda:0")
-            out = torch.zeros((B, 2, H, W), device="cuda:0")
+            # NaN-filled, not zero-filled: the library must write (or zero) every element itself
+            count = torch.full((B, 1, H, W), float("nan"), device="cuda:0")
+            out = torch.full((B, 2, H, W), float("nan"), device="cuda:0")
             assert cabi.flowprojection_forward(gpu(torch, fq), count, out, fh) == 0
             ref, rcount = oracle.flowproj_fwd(fq, fh)
             assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref), (B, H, W, kind, fh)
-            count.zero_(), out.zero_()
+            count.fill_(float("nan")), out.fill_(float("nan"))
             assert cabi.depthflowprojection_forward(gpu(torch, fq), gpu(torch, depth), count, out, fh) == 0
             ref, rcount = oracle.depthflowproj_fwd(fq, depth, fh)
             assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref), (B, H, W, kind, fh)

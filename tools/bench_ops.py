@@ -68,20 +68,24 @@ def main():
                 print("fi3   %-8s %-6s %8.4f ms %8.1f GB/s" % (model, tag, ms, 96.0 * px / ms / 1e6), flush=True)
 
         def fp():
-            count.zero_()
-            proj.zero_()
             cabi.flowprojection_forward(flow, count, proj, 1)
 
         def dfp():
-            count.zero_()
-            proj.zero_()
             cabi.depthflowprojection_forward(flow, depth, count, proj, 1)
         if "proj" in ops:
             ms = timed(fp, args.iters * 2)
-            print("proj  %-8s        %8.4f ms %8.1f GB/s (incl. 2 zero fills)" % (model, ms, 20.0 * px / ms / 1e6), flush=True)
+            print("proj  %-8s        %8.4f ms %8.1f GB/s (all launches)" % (model, ms, 20.0 * px / ms / 1e6), flush=True)
         if "dproj" in ops:
             ms = timed(dfp, args.iters * 2)
-            print("dproj %-8s        %8.4f ms %8.1f GB/s (incl. 2 zero fills)" % (model, ms, 24.0 * px / ms / 1e6), flush=True)
+            print("dproj %-8s        %8.4f ms %8.1f GB/s (all launches)" % (model, ms, 24.0 * px / ms / 1e6), flush=True)
+    for thr in ([256, 1 << 40, 0] if "corrknob" in ops else []):
+        cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
+        cabi.lib().vfi_debug_correlation(thr)
+        for a, b in S.correlation_features(1, h, w, S.generator()):
+            a, b = a.to(dev), b.to(dev)
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            print("corr thr=%-14d C=%-3d %4dx%-4d %8.4f ms" % (thr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
+        cabi.lib().vfi_debug_correlation(256)
     if "corr" in ops:
         tot_ms, tot_b = 0.0, 0.0
         for a, b in S.correlation_features(1, h, w, gen):

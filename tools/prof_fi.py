@@ -18,7 +18,12 @@ h, w = S.padded_size(1080, 1920)
 gen = S.generator()
 img = (S.context(1, C, h, w, gen) if C != 3 else S.frames(1, h, w, gen)).to(dev)
 filt = S.filters(1, h, w, gen).to(dev)
-flow = S.flow(1, h, w, 8.0, gen, model).to(dev)
+if model == "invalid":       # |fx| >= W/2 everywhere: pure copy-through, known traffic (C planes in + out, flow)
+    flow = torch.full((1, 2, h, w), float(w), device=dev)
+elif model == "zero":        # windows = tile + 3: known staging pattern
+    flow = torch.zeros((1, 2, h, w), device=dev)
+else:
+    flow = S.flow(1, h, w, 8.0, gen, model).to(dev)
 out = torch.empty_like(img)
 for _ in range(4):
     assert cabi.filterinterp_forward_ori(img, flow, filt, out) == 0

@@ -13,13 +13,14 @@
 // an index test, and for the configuration PWC-Net uses (k=1, s1=s2=1) a
 // workgroup owns a 32x8 tile of output pixels, stages the matching window of
 // the second feature map (tile + 2*md halo) in LDS one channel chunk at a
-// time, and each lane keeps all (2*md+1)^2 running sums in registers.
+// time, and each lane keeps all (2*md+1)^2 running sums in registers.  The coarser pyramid
+// levels (hundreds to a few thousand pixels, up to 196 channels) would leave most of the chip
+// idle that way; they use 16x4-pixel tiles with one WAVE PER DISPLACEMENT ROW (9 waves per
+// workgroup, 9 running sums per lane), which spreads the same work over 9x more waves.
 #include "vfi_common.h"
 
 namespace vfi {
 
-#define CORR_TW 32
-#define CORR_TH 8
 #define CORR_CC 8       // channels staged per LDS fill
 
 __device__ __forceinline__ float padded_at(const float* __restrict__ f, int h, int w, int y, int x) {
@@ -28,16 +29,16 @@ __device__ __forceinline__ float padded_at(const float* __restrict__ f, int h, i
 
 // k == 1, stride1 == stride2 == 1.  `org` = md - pad: output pixel (oy, ox) is
 // centred on input pixel (oy + org, ox + org).
-template <int MD>
+template <int MD, int CORR_TW, int CORR_TH>
 __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
     int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     constexpr int LW = CORR_TW + 2 * MD, LH = CORR_TH + 2 * MD;
+    constexpr int NI = (LH + CORR_TH - 1) / CORR_TH, NJ = (LW + CORR_TW - 1) / CORR_TW;
     __shared__ float tile[CORR_CC][LH][LW];
 
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * CORR_TW + tx;
     const int ox = blockIdx.x * CORR_TW + tx, oy = blockIdx.y * CORR_TH + ty;
     const int b = blockIdx.z;
     const int64_t plane = (int64_t)h * w;
@@ -51,25 +52,48 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
 #pragma unroll
     for (int k = 0; k < D * D; ++k) acc[k] = 0.0f;
 
-    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
-        __syncthreads();
-        for (int idx = tid; idx < CORR_CC * LH * LW; idx += CORR_TW * CORR_TH) {
-            const int c = idx / (LH * LW);
-            const int rem = idx - c * (LH * LW);
-            const int r = rem / LW, col = rem - r * LW;
-            float v = 0.0f;
-            if (c0 + c < channel) v = padded_at(f2 + (int64_t)(c0 + c) * plane, h, w, wy0 + r, wx0 + col);
-            (&tile[0][0][0])[idx] = v;
+    // staging plan of this thread, the same for every channel: window rows ty + i*TH, columns
+    // tx + j*TW -- row segments, no index arithmetic per element; zero padding is the bounds test
+    int soff[NI][NJ];
+    bool sin[NI][NJ], sok[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = ty + i * CORR_TH, col = tx + j * CORR_TW;
+            const int gy = wy0 + r, gx = wx0 + col;
+            sin[i][j] = r < LH && col < LW;
+            sok[i][j] = sin[i][j] && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            soff[i][j] = sok[i][j] ? gy * w + gx : 0;
         }
-        __syncthreads();
+    const bool f1ok = y1 >= 0 && y1 < h && x1 >= 0 && x1 < w;
+    const int f1off = f1ok ? y1 * w + x1 : 0;
+
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
         const int cn = min(CORR_CC, channel - c0);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CORR_CC; ++c) {
+            const float* p = f2 + (int64_t)(c0 + c) * plane;
+            const bool cok = c < cn;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (sin[i][j]) tile[c][ty + i * CORR_TH][tx + j * CORR_TW] = (cok && sok[i][j]) ? p[soff[i][j]] : 0.0f;
+        }
+        float a[CORR_CC];
+#pragma unroll
+        for (int c = 0; c < CORR_CC; ++c)
+            a[c] = (c < cn && f1ok) ? f1[(int64_t)(c0 + c) * plane + f1off] : 0.0f;
+        __syncthreads();
         for (int c = 0; c < cn; ++c) {
-            const float a = padded_at(f1 + (int64_t)(c0 + c) * plane, h, w, y1, x1);
+            const float av = a[c];
 #pragma unroll
             for (int tj = 0; tj < D; ++tj)
 #pragma unroll
                 for (int ti = 0; ti < D; ++ti)
-                    acc[tj * D + ti] = fmaf(a, tile[c][ty + tj][tx + ti], acc[tj * D + ti]);
+                    acc[tj * D + ti] = fmaf(av, tile[c][ty + tj][tx + ti], acc[tj * D + ti]);
         }
     }
     if (ox < ow && oy < oh) {
@@ -77,6 +101,73 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
         float* o = out + (int64_t)b * (D * D) * oh * ow + (int64_t)oy * ow + ox;
 #pragma unroll
         for (int k = 0; k < D * D; ++k) o[(int64_t)k * oh * ow] = acc[k] / nelems;
+    }
+}
+
+// k == 1, strides 1, small frames: tile of 16x4 output pixels, threadIdx.y = displacement row tj.
+template <int MD>
+__global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
+    int channel, int h, int w, int oh, int ow, int org) {
+    constexpr int D = 2 * MD + 1;
+    constexpr int TW = 16, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;
+    constexpr int NT = 64 * D, NE = CORR_CC * LH * LW;      // threads, staged elements per chunk
+    constexpr int NPT = (NE + NT - 1) / NT;
+    __shared__ float tile[CORR_CC][LH][LW];
+    __shared__ float f1s[CORR_CC][TH * TW];
+
+    const int lane = threadIdx.x, tj = threadIdx.y;          // lane = pixel inside the tile
+    const int tid = tj * 64 + lane;
+    const int px = lane & (TW - 1), py = lane >> 4;
+    const int ox = blockIdx.x * TW + px, oy = blockIdx.y * TH + py;
+    const int b = blockIdx.z;
+    const int64_t plane = (int64_t)h * w;
+    const float* f1 = in1 + (int64_t)b * channel * plane;
+    const float* f2 = in2 + (int64_t)b * channel * plane;
+    const int y1 = oy + org, x1 = ox + org;
+    const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;
+
+    // staging plan: flat element e = tid + k*NT of the chunk's [CC][LH][LW] block (constant divisors)
+    int soff[NPT], sch[NPT];
+    bool sok[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (LH * LW), rem = e - c * (LH * LW);
+        const int r = rem / LW, col = rem - r * LW;
+        const int gy = wy0 + r, gx = wx0 + col;
+        sch[k] = c;
+        sok[k] = e < NE && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = sok[k] ? gy * w + gx : 0;
+    }
+    const bool f1ok = y1 >= 0 && y1 < h && x1 >= 0 && x1 < w;
+    const int f1off = f1ok ? y1 * w + x1 : 0;
+
+    float acc[D];
+#pragma unroll
+    for (int ti = 0; ti < D; ++ti) acc[ti] = 0.0f;
+
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
+        const int cn = min(CORR_CC, channel - c0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < NE) (&tile[0][0][0])[e] = (sok[k] && sch[k] < cn) ? f2[(int64_t)(c0 + sch[k]) * plane + soff[k]] : 0.0f;
+        }
+        if (tj < CORR_CC) f1s[tj][lane] = (tj < cn && f1ok) ? f1[(int64_t)(c0 + tj) * plane + f1off] : 0.0f;
+        __syncthreads();
+        for (int c = 0; c < cn; ++c) {
+            const float av = f1s[c][lane];
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti) acc[ti] = fmaf(av, tile[c][py + tj][px + ti], acc[ti]);
+        }
+    }
+    if (ox < ow && oy < oh) {
+        const float nelems = (float)channel;
+        float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
+#pragma unroll
+        for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[ti] / nelems;
     }
 }
 
@@ -169,6 +260,10 @@ __global__ __launch_bounds__(256) void corr_backward(
 
 using namespace vfi;
 
+// development knob: number of 32x8 tiles from which the one-lane-per-pixel kernel is used
+static long long g_corr_big_threshold = 256;
+extern "C" void vfi_debug_correlation(long long big_threshold) { g_corr_big_threshold = big_threshold; }
+
 extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
                                             int stride1, int stride2, int* out_channels, int* out_h, int* out_w) {
     if (kernel_size <= 0 || stride1 <= 0 || stride2 <= 0 || max_displacement < 0 || pad_size < 0) return VFI_ERR_SHAPE;
@@ -193,9 +288,16 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
     hipStream_t st = (hipStream_t)stream;
     const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
     if (kernel_size == 1 && stride1 == 1 && stride2 == 1 && max_displacement == 4) {
-        const dim3 grid((ow + CORR_TW - 1) / CORR_TW, (oh + CORR_TH - 1) / CORR_TH, batch);
-        hipLaunchKernelGGL(corr_forward_k1<4>, grid, dim3(CORR_TW, CORR_TH, 1), 0, st, input1, input2, output,
-                           channel, h, w, oh, ow, max_displacement - pad_size);
+        const int64_t big_tiles = (int64_t)((ow + 31) / 32) * ((oh + 7) / 8) * batch;
+        if (big_tiles >= g_corr_big_threshold) {
+            const dim3 grid((ow + 31) / 32, (oh + 7) / 8, batch);
+            hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, input1, input2, output,
+                               channel, h, w, oh, ow, max_displacement - pad_size);
+        } else {
+            const dim3 grid((ow + 15) / 16, (oh + 3) / 4, batch);
+            hipLaunchKernelGGL(corr_forward_k1_rows<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
+                               channel, h, w, oh, ow, max_displacement - pad_size);
+        }
     } else {
         const int64_t total = (int64_t)batch * oc * oh * ow;
         hipLaunchKernelGGL(corr_forward_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,

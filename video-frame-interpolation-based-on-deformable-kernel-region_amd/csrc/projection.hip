@@ -22,8 +22,11 @@
 //                   its tile in LDS from the row segments on its list (one wave per
 //                   segment), then writes count and the normalised flow once,
 //                   coalesced.
+//   Z  proj_zero    only does work on the fallback path (zero-fills count / output).
 //   C  proj_average only does work on the fallback path.
 //   D  proj_fillhole
+// Launch order A, Z, B, C, D.  B writes every cell of count and output, so callers need not
+// zero-fill them (the reference's callers must: its splat accumulates into them).
 // Fallback: when any list overflows (fields with displacements of many tiles,
 // e.g. random flow of +-W/2), B instead splats its own source tile with global
 // atomics exactly like the reference, and C normalises.  The switch is a serial
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     if (tid < 3) rec[tid] = 0;                              // ... leave it empty for the next call
 
     if (fallback) {
-        // the reference's own scheme: this tile as SOURCE tile, global atomics into the zero-filled planes
+        // the reference's own scheme: this tile as SOURCE tile, global atomics into the planes Z zeroed
         float* o0 = out + (int64_t)b * s1.b;
         float* o1 = o0 + s1.c;
         float* cn = count + (int64_t)b * sc.b;
@@ -317,6 +320,23 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
             o[s1.c] = vy;
             count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
         }
+    }
+}
+
+// Z: zero fill for the fallback path's atomics (otherwise 512 workgroups that return at once)
+__global__ __launch_bounds__(256) void proj_zero(
+    float* __restrict__ count, float* __restrict__ out, int batch, int h, int w, vfi_strides s1, vfi_strides sc,
+    const int* __restrict__ ws, int serial) {
+    if (ws[0] != serial) return;
+    const int64_t total = (int64_t)batch * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int b = (int)(i / ((int64_t)w * h));
+        count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = 0.0f;
+        float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+        o[0] = 0.0f;
+        o[s1.c] = 0.0f;
     }
 }
 
@@ -540,6 +560,8 @@ static int project_forward(const float* in1, const float* in2, float* count, flo
     if (!ws) return VFI_ERR_LAUNCH;
     hipLaunchKernelGGL(proj_bin<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, g, s1, s2, ws->words,
                        ws->bits, ws->serial);
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    hipLaunchKernelGGL(proj_zero, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     hipLaunchKernelGGL(proj_gather<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, count, out, g, s1, s2,
                        sc, ws->words, ws->bits, ws->serial);

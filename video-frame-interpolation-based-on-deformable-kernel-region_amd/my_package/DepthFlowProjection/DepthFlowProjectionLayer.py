@@ -14,9 +14,10 @@ class DepthFlowProjectionLayer(Function):
         assert input2.is_contiguous()
         require_gpu(input1, input2)
         fillhole = 1 if requires_grad == False else 0     # noqa: E712
-        count = torch.zeros((input1.size(0), 1, input1.size(2), input1.size(3)), dtype=torch.float32,
+        # (the reference zero-fills both; this library writes every element)
+        count = torch.empty((input1.size(0), 1, input1.size(2), input1.size(3)), dtype=torch.float32,
                             device=input1.device)
-        output = torch.zeros_like(input1)
+        output = torch.empty_like(input1)
         err = my_lib.DepthFlowProjectionLayer_gpu_forward(input1, input2, count, output, fillhole)
         if err != 0:
             print(err)

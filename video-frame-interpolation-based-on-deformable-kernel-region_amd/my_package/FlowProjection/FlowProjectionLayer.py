@@ -13,10 +13,11 @@ class FlowProjectionLayer(Function):
         assert input1.is_contiguous()
         require_gpu(input1)
         fillhole = 1 if requires_grad == False else 0     # noqa: E712  (reference :23)
-        # accumulated into by the kernels: must start from zero (reference :35-36)
-        count = torch.zeros((input1.size(0), 1, input1.size(2), input1.size(3)), dtype=torch.float32,
+        # the reference zero-fills both (:35-36) because its kernels accumulate into them; this
+        # library writes every element, so plain allocations do
+        count = torch.empty((input1.size(0), 1, input1.size(2), input1.size(3)), dtype=torch.float32,
                             device=input1.device)
-        output = torch.zeros_like(input1)
+        output = torch.empty_like(input1)
         err = my_lib.FlowProjectionLayer_gpu_forward(input1, count, output, fillhole)
         if err != 0:
             print(err)
