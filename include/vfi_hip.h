@@ -80,6 +80,19 @@ int vfi_filterinterp_forward_defor(int variant,
                                    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
                                    vfi_stream_t stream);
 
+/* backward of the same three variants: FilterInterpolationLayer_gpu_backward (cc:93-187),
+ * ..._backward_deforconv (cc:273-367), ..._backward_nofilterwithdeforconv (cc:448-533).
+ * gradinput1..4 must arrive zeroed.  variant 2: input3 / gradinput3 are the offset field and its
+ * gradient, input4 / gradinput4 unused (NULL).  gradoutput is addressed with input1's strides,
+ * gradinput_k with input_k's, as in the reference. */
+int vfi_filterinterp_backward_defor(int variant,
+                                    const float* input1, const float* input2, const float* input3,
+                                    const float* input4, const float* gradoutput,
+                                    float* gradinput1, float* gradinput2, float* gradinput3, float* gradinput4,
+                                    int batch, int channel, int h, int w, int filter_size,
+                                    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                    vfi_stream_t stream);
+
 /* ---- flowprojection_cuda -----------------------------------------------------
  * replaces FlowProjectionLayer_gpu_forward / _backward (flowprojection_cuda.cc:9-57, 59-114).
  * count [B,1,H,W] and output [B,2,H,W] are fully written (no zero fill needed).

@@ -98,6 +98,25 @@ def filterinterp_defor_fwd(variant, img, flow, filt, off, fmad=0):
     return out
 
 
+def filterinterp_defor_bwd(variant, img, flow, filt, off, gout, fmad=0):
+    """Returns (gimg, gflow, gfilt or None, goff)."""
+    img, flow, off, gout = _f32(img), _f32(flow), _f32(off), _f32(gout)
+    B, C, H, W = img.shape
+    gimg, gflow, goff = np.zeros_like(img), np.zeros_like(flow), np.zeros_like(off)
+    if variant != 2:
+        filt = _f32(filt)
+        fs = int(np.sqrt(np.float32(filt.shape[1])))
+        gfilt = np.zeros_like(filt)
+        fp, gfp = _p(filt), _p(gfilt)
+    else:
+        fs = int(np.sqrt(np.float32(off.shape[1] // 2)))
+        gfilt, fp, gfp = None, None, None
+    _check(lib().vfi_oracle_filterinterp_defor_bwd(int(variant), _p(img), _p(flow), fp, _p(off), _p(gout), _p(gimg),
+                                                   _p(gflow), gfp, _p(goff), B, C, H, W, fs, int(fmad)),
+           "filterinterp_defor_bwd")
+    return gimg, gflow, gfilt, goff
+
+
 def flowproj_fwd(flow, fillhole=1):
     flow = _f32(flow)
     B, _, H, W = flow.shape

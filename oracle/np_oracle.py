@@ -129,6 +129,64 @@ def filterinterp_defor_fwd(variant, img, flow, filt, off):
     return np.where(valid[:, None], out, img).astype(f32)
 
 
+def filterinterp_defor_bwd(variant, img, flow, filt, off, gout):
+    """float64 formulation of the deformable backwards; returns (gimg, gflow, gfilt or None, goff)."""
+    img, flow, off, gout = (a.astype(np.float64) for a in (img, flow, off, gout))
+    B, C, H, W = img.shape
+    if variant == 2:
+        fs = int(np.sqrt(f32(off.shape[1] // 2)))
+        filt = None
+    else:
+        filt = filt.astype(np.float64)
+        fs = int(np.sqrt(f32(filt.shape[1])))
+    fs2 = fs * fs
+    valid, x2, y2, ix, iy, alpha, beta, L, T = _fi_geometry(flow.astype(f32), H, W, fs)
+    x2, y2, alpha, beta = (a.astype(np.float64) for a in (x2, y2, alpha, beta))
+    kq = [(1 - alpha) * (1 - beta), alpha * (1 - beta), (1 - alpha) * beta, alpha * beta]
+    gimg = np.zeros((B, C, H * W))
+    gfilt = None if filt is None else np.zeros_like(filt)
+    goff = np.zeros_like(off)
+    q = [np.zeros((B, C, H, W)) for _ in range(4)]
+    bidx = np.arange(B)[:, None, None]
+    for dj in range(fs):
+        for di in range(fs):
+            k = dj * fs + di
+            j, i = T + dj, L + di
+            cj, ci = np.clip(j, 0, H - 1), np.clip(i, 0, W - 1)
+            fracY = (cj.astype(f32) + off[:, k].astype(f32)).astype(np.float64)
+            fracX = (ci.astype(f32) + off[:, fs2 + k].astype(f32)).astype(np.float64)
+            if variant == 0:
+                quad = (j > iy) * 2 + (i > ix)
+            else:
+                quad = np.where(fracY <= y2, 0, 2) + np.where(fracX <= x2, 0, 1)
+            top, left = np.trunc(fracY).astype(np.int64), np.trunc(fracX).astype(np.int64)
+            phiY, phiX = (fracY - top)[:, None], (fracX - left)[:, None]
+            t, bo = np.clip(top, 0, H - 1), np.clip(top + 1, 0, H - 1)
+            l, r = np.clip(left, 0, W - 1), np.clip(left + 1, 0, W - 1)
+            vTL, vTR, vBL, vBR = _gather(img, t, l), _gather(img, t, r), _gather(img, bo, l), _gather(img, bo, r)
+            v = (1 - phiX) * (1 - phiY) * vTL + phiX * (1 - phiY) * vTR + (1 - phiX) * phiY * vBL + phiX * phiY * vBR
+            dY = -(1 - phiX) * vTL + (1 - phiX) * vBL - phiX * vTR + phiX * vBR
+            dX = -(1 - phiY) * vTL + (1 - phiY) * vTR - phiY * vBL + phiY * vBR
+            wq = np.choose(quad, kq) * valid                         # [B,H,W]
+            wgt = 1.0 if filt is None else filt[:, k]
+            gw = gout * wq[:, None]                                   # [B,C,H,W]
+            idx = (cj * W + ci).reshape(B, 1, H * W)
+            for b in range(B):
+                for c in range(C):
+                    np.add.at(gimg[b, c], idx[b, 0], (gw[b, c] * (wgt if filt is None else wgt[b])).reshape(-1))
+            if filt is not None:
+                gfilt[:, k] = (gw * v).sum(1)
+            goff[:, k] = (gw * dY).sum(1) * wgt
+            goff[:, fs2 + k] = (gw * dX).sum(1) * wgt
+            for n in range(4):
+                q[n] += np.where((quad == n)[:, None], v * (wgt if filt is None else wgt[:, None]), 0.0)
+    a, b_ = alpha[:, None], beta[:, None]
+    gx = (gout * ((1 - b_) * (q[1] - q[0]) + b_ * (q[3] - q[2]))).sum(1) * valid
+    gy = (gout * ((1 - a) * (q[2] - q[0]) + a * (q[3] - q[1]))).sum(1) * valid
+    gflow = np.stack([gx, gy], 1)
+    return gimg.reshape(B, C, H, W), gflow, gfilt, goff
+
+
 def _project_targets(flow, H, W):
     B = flow.shape[0]
     xs, ys = _grid(B, H, W)

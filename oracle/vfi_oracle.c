@@ -316,6 +316,117 @@ int vfi_oracle_filterinterp_defor_fwd(int variant, const float* img, const float
     return 0;
 }
 
+/* backward of the three deformable variants (filterinterpolation_cuda_kernel.cu:430-1215,
+ * 1500-1935, 2195-2567).  Per valid pixel and tap k: quadrant weight Wq chosen by integer index
+ * (variant 0) or by displaced position (variants 1, 2);
+ *   gimg[clamped UNDISPLACED tap] += g*Wq * filt[k]      (the reference's own approximation)
+ *   gfilt[k]                      += g*Wq * tap_value
+ *   goff_y[k], goff_x[k]          += g*Wq * d(tap_value)/d(offset) * filt[k]
+ *   gflow = quadrant differences of the forward sums, as in the _ori backward.
+ * Variant 2 has no filter: filt == NULL, gfilt == NULL, weights are 1. */
+int vfi_oracle_filterinterp_defor_bwd(int variant, const float* img, const float* flow,
+                                      const float* filt, const float* off, const float* gout,
+                                      float* gimg, float* gflow, float* gfilt, float* goff,
+                                      int B, int C, int H, int W, int fs, int fmad) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || fs <= 0 || variant < 0 || variant > 2) return 1;
+    const i64 HW = (i64)H * W;
+    const int fs2 = fs * fs;
+    for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+        const i64 px = (i64)y * W + x;
+        const float fx = flow[((i64)b * 2 + 0) * HW + px];
+        const float fy = flow[((i64)b * 2 + 1) * HW + px];
+        const float x2 = (float)x + fx;
+        const float y2 = (float)y + fy;
+        if (!fi_valid(fx, fy, x2, y2, W, H)) continue;
+        const int ix = (int)x2, iy = (int)y2;
+        const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+        const float alpha = x2 - (float)ix;
+        const float beta = y2 - (float)iy;
+        const float* opx = off + (i64)b * 2 * fs2 * HW + px;
+        const float* fpx = (variant == 2) ? NULL : filt + (i64)b * fs2 * HW + px;
+        float* gfpx = (variant == 2) ? NULL : gfilt + (i64)b * fs2 * HW + px;
+        float* gopx = goff + (i64)b * 2 * fs2 * HW + px;
+        const float kq[4] = { (1.0f - alpha) * (1.0f - beta), alpha * (1.0f - beta),
+                              (1.0f - alpha) * beta,          alpha * beta };
+        float gx = 0.0f, gy = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float* plane = img + ((i64)b * C + c) * HW;
+            float* gplane = gimg + ((i64)b * C + c) * HW;
+            const float g = gout[((i64)b * C + c) * HW + px];
+            const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
+                                  g * (1.0f - alpha) * beta,          g * alpha * beta };
+            float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int dj = 0; dj < fs; ++dj) {
+                const int j = T + dj, cj = clampi(j, 0, H - 1);
+                for (int di = 0; di < fs; ++di) {
+                    const int i = L + di, ci = clampi(i, 0, W - 1);
+                    const int k = dj * fs + di;
+                    const float fracY = (float)cj + opx[(i64)k * HW];
+                    const float fracX = (float)ci + opx[(i64)(fs2 + k) * HW];
+                    int quad;
+                    if (variant == 0) quad = (j > iy ? 2 : 0) + (i > ix ? 1 : 0);
+                    else if (fracX <= x2 && fracY <= y2) quad = 0;
+                    else if (fracX > x2 && fracY <= y2) quad = 1;
+                    else if (fracX <= x2 && fracY > y2) quad = 2;
+                    else if (fracX > x2 && fracY > y2) quad = 3;
+                    else continue;                              /* NaN position: no quadrant */
+                    const float wgt = (variant == 2) ? 1.0f : fpx[(i64)k * HW];
+                    /* tap value and its derivatives w.r.t. the offsets; corners clamped as in the forward */
+                    const int Top = (int)fracY, Left = (int)fracX;
+                    const float phiY = fracY - (float)Top, phiX = fracX - (float)Left;
+                    const int t = clampi(Top, 0, H - 1), bo = clampi(Top + 1, 0, H - 1);
+                    const int l = clampi(Left, 0, W - 1), r = clampi(Left + 1, 0, W - 1);
+                    const float vTL = plane[(i64)t * W + l], vTR = plane[(i64)t * W + r];
+                    const float vBL = plane[(i64)bo * W + l], vBR = plane[(i64)bo * W + r];
+                    float v = ((1.0f - phiX) * (1.0f - phiY)) * vTL;
+                    v = mac(phiX * (1.0f - phiY), vTR, v, fmad);
+                    v = mac((1.0f - phiX) * phiY, vBL, v, fmad);
+                    v = mac(phiY * phiX, vBR, v, fmad);
+                    float dY = (-(1.0f - phiX)) * vTL;          /* - (1-phiX) TL + (1-phiX) BL - phiX TR + phiX BR */
+                    dY = mac(1.0f - phiX, vBL, dY, fmad);
+                    dY = mac(-phiX, vTR, dY, fmad);
+                    dY = mac(phiX, vBR, dY, fmad);
+                    float dX = (-(1.0f - phiY)) * vTL;          /* - (1-phiY) TL + (1-phiY) TR - phiY BL + phiY BR */
+                    dX = mac(1.0f - phiY, vTR, dX, fmad);
+                    dX = mac(-phiY, vBL, dX, fmad);
+                    dX = mac(phiY, vBR, dX, fmad);
+                    if (variant == 2) {
+                        gplane[(i64)cj * W + ci] += qg[quad];
+                        q[quad] = q[quad] + v;
+                        gopx[(i64)k * HW] += g * kq[quad] * dY;
+                        gopx[(i64)(fs2 + k) * HW] += g * kq[quad] * dX;
+                    } else {
+                        gplane[(i64)cj * W + ci] += qg[quad] * wgt;
+                        gfpx[(i64)k * HW] += qg[quad] * v;
+                        q[quad] = mac(v, wgt, q[quad], fmad);
+                        gopx[(i64)k * HW] += g * kq[quad] * dY * wgt;
+                        gopx[(i64)(fs2 + k) * HW] += g * kq[quad] * dX * wgt;
+                    }
+                }
+            }
+            {
+                const float gamma = 1.0f - beta;
+                float temp = 0.0f;
+                temp = mac(gamma, q[1] - q[0], temp, fmad);
+                temp = mac(1.0f - gamma, q[3] - q[2], temp, fmad);
+                gx = mac(g, temp, gx, fmad);
+            }
+            {
+                const float gamma = 1.0f - alpha;
+                float temp = 0.0f;
+                temp = mac(gamma, q[2] - q[0], temp, fmad);
+                temp = mac(1.0f - gamma, q[3] - q[1], temp, fmad);
+                gy = mac(g, temp, gy, fmad);
+            }
+        }
+        gflow[((i64)b * 2 + 0) * HW + px] = gx;
+        gflow[((i64)b * 2 + 1) * HW + px] = gy;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------ A3 / A4 */
 
 /* pass 3 of both projections (flowprojection_cuda_kernel.cu:175-231,

@@ -50,6 +50,13 @@ int vfi_oracle_filterinterp_defor_fwd(int variant, const float* img, const float
                                       const float* filt, const float* off, float* out,
                                       int B, int C, int H, int W, int fs, int fmad);
 
+/* backward of the same three variants (:430-1215, :1500-1935, :2195-2567); grads arrive zeroed;
+ * variant 2: filt and gfilt are NULL. */
+int vfi_oracle_filterinterp_defor_bwd(int variant, const float* img, const float* flow,
+                                      const float* filt, const float* off, const float* gout,
+                                      float* gimg, float* gflow, float* gfilt, float* goff,
+                                      int B, int C, int H, int W, int fs, int fmad);
+
 /* A3  flowprojection_cuda_kernel.cu:29-235 ; count/out must arrive zero-filled */
 int vfi_oracle_flowproj_fwd(const float* flow, float* count, float* out,
                             int B, int H, int W, int fillhole);

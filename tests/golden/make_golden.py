@@ -54,6 +54,10 @@ def main():
     g["fi_gimg"], g["fi_gflow"], g["fi_gfilt"] = o.filterinterp_ori_bwd(img, flow, filt, gout)
     for v, name in ((0, "offset"), (1, "region"), (2, "nofilter")):
         g["fi_out_" + name] = o.filterinterp_defor_fwd(v, img, flow, filt, off)
+        d = o.filterinterp_defor_bwd(v, img, flow, filt, off, gout)
+        for arr, n in zip(d, ("gimg", "gflow", "gfilt", "goff")):
+            if arr is not None:
+                g["fi_%s_%s" % (n, name)] = arr
     filt5 = rng.random((1, 25, H, W), dtype=np.float32)
     g["fi5_filt"] = filt5
     g["fi5_out"] = o.filterinterp_ori_fwd(img[:1], flow[:1], filt5)

@@ -65,7 +65,9 @@ def test_ctypes_table_matches_header(built):
 REFERENCE_EXPORTS = {
     "filterinterpolation_cuda": ["FilterInterpolationLayer_gpu_forward_ori", "FilterInterpolationLayer_gpu_backward_ori",
                                  "FilterInterpolationLayer_gpu_forward", "FilterInterpolationLayer_gpu_forward_deforconv",
-                                 "FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv"],
+                                 "FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv",
+                                 "FilterInterpolationLayer_gpu_backward", "FilterInterpolationLayer_gpu_backward_deforconv",
+                                 "FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv"],
     "flowprojection_cuda": ["FlowProjectionLayer_gpu_forward", "FlowProjectionLayer_gpu_backward"],
     "depthflowprojection_cuda": ["DepthFlowProjectionLayer_gpu_forward", "DepthFlowProjectionLayer_gpu_backward"],
     "interpolation_cuda": ["InterpolationLayer_gpu_forward", "InterpolationLayer_gpu_backward"],

@@ -172,6 +172,40 @@ def test_deformable_forward_bit_exact(torch_mod, cabi, oracle, variant, fs):
         assert np.array_equal(cpu(out), ref)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("fs", [4, 6, 3])
+def test_deformable_backward(torch_mod, cabi, oracle, variant, fs):
+    """gflow / gfilt / goff cells belong to one pixel: bit-exact.  gimg is an atomic scatter: 1e-4."""
+    torch = torch_mod
+    rng = np.random.default_rng(70 + variant + fs)
+    B, C, H, W = 2, 3, 20, 70
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 2.0)
+    flow[0, 0, 3, 3] = W                                       # invalid pixel: no gradient at all
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    for scale in (0.5, 3.0):
+        off = rng.uniform(-scale, scale, (B, 2 * fs * fs, H, W)).astype(f32)
+        g1 = torch.zeros((B, C, H, W), device="cuda:0")
+        g2 = torch.zeros((B, 2, H, W), device="cuda:0")
+        go = torch.zeros((B, 2 * fs * fs, H, W), device="cuda:0")
+        if variant == 2:
+            err = cabi.filterinterp_backward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, off), None,
+                                                   gpu(torch, gout), g1, g2, go, None)
+        else:
+            gf = torch.zeros((B, fs * fs, H, W), device="cuda:0")
+            err = cabi.filterinterp_backward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, filt),
+                                                   gpu(torch, off), gpu(torch, gout), g1, g2, gf, go)
+        assert err == 0
+        r1, r2, r3, r4 = oracle.filterinterp_defor_bwd(variant, img, flow, filt, off, gout, fmad=1)
+        assert np.abs(cpu(g1) - r1).max() <= 1e-4
+        assert np.array_equal(cpu(g2), r2)
+        assert np.array_equal(cpu(go), r4)
+        if variant != 2:
+            assert np.array_equal(cpu(gf), r3)
+        assert not cpu(go)[0, :, 3, 3].any() and not cpu(g2)[0, :, 3, 3].any()
+
+
 # ------------------------------------------------------------------ projections
 
 @pytest.mark.parametrize("B,H,W", [(1, 32, 48), (2, 17, 70), (1, 1, 1), (1, 40, 200)])
@@ -397,6 +431,16 @@ def test_against_golden_fixtures(torch_mod, cabi, golden_dir):
         a3, a4 = (off, None) if v == 2 else (filt, off)
         assert cabi.filterinterp_forward_defor(v, img, flow, a3, a4, out) == 0
         assert close(cpu(out), g["fi_out_" + name])
+        grads = [torch.zeros_like(t) for t in ((img, flow, off) if v == 2 else (img, flow, filt, off))]
+        if v == 2:
+            assert cabi.filterinterp_backward_defor(v, img, flow, off, None, gpu(torch, g["fi_gout"]),
+                                                    grads[0], grads[1], grads[2], None) == 0
+            names = ("gimg", "gflow", "goff")
+        else:
+            assert cabi.filterinterp_backward_defor(v, img, flow, filt, off, gpu(torch, g["fi_gout"]), *grads) == 0
+            names = ("gimg", "gflow", "gfilt", "goff")
+        for t, n in zip(grads, names):
+            assert close(cpu(t), g["fi_%s_%s" % (n, name)], 1e-4), (name, n)
     out5 = torch.zeros_like(img[:1])
     assert cabi.filterinterp_forward_ori(img[:1].contiguous(), flow[:1].contiguous(), gpu(torch, g["fi5_filt"]), out5) == 0
     assert close(cpu(out5), g["fi5_out"])
@@ -475,9 +519,16 @@ def test_wrapper_mirrors_match_cabi(torch_mod, cabi, oracle):
 
     for mode, variant in (("offset", 0), ("deforconv", 1), ("nofilter", 2)):
         m = FilterInterpolationDeformableModule(mode)
-        with torch.no_grad():
-            o = m(img, flow, gpu(torch, off_np)) if variant == 2 else m(img, flow, filt, gpu(torch, off_np))
+        i2, f2, w2 = (gpu(torch, a).requires_grad_(True) for a in (img_np, flow_np, filt_np))
+        o2 = gpu(torch, off_np).requires_grad_(True)
+        o = m(i2, f2, o2) if variant == 2 else m(i2, f2, w2, o2)
         assert np.array_equal(cpu(o), oracle.filterinterp_defor_fwd(variant, img_np, flow_np, filt_np, off_np, fmad=1))
+        o.backward(gpu(torch, gout_np))
+        d1, d2, d3, d4 = oracle.filterinterp_defor_bwd(variant, img_np, flow_np, filt_np, off_np, gout_np, fmad=1)
+        assert np.abs(cpu(i2.grad) - d1).max() <= 1e-4
+        assert np.array_equal(cpu(f2.grad), d2) and np.array_equal(cpu(o2.grad), d4)
+        if variant != 2:
+            assert np.array_equal(cpu(w2.grad), d3)
 
     fq = (np.round(flow_np * 8) / 8).astype(f32)
     # requires_grad=False -> fillhole (inference); True -> no fillhole (FlowProjectionLayer.py:23)

@@ -247,6 +247,56 @@ def test_filterinterp_backward_properties(oracle, np_oracle):
     assert np.abs(np.where(valid, gy, 0) - gflow[:, 1]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("fs", [4, 3])
+def test_deformable_backward_properties(oracle, np_oracle, variant, fs):
+    rng = np.random.default_rng(100 + variant * 10 + fs)
+    B, C, H, W = 2, 3, 12, 16
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 2.0)
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    off = rng.uniform(-0.9, 0.9, (B, 2 * fs * fs, H, W)).astype(f32)
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    gimg, gflow, gfilt, goff = oracle.filterinterp_defor_bwd(variant, img, flow, filt, off, gout)
+    # 1. independent float64 formulation of all four gradients
+    n_gimg, n_gflow, n_gfilt, n_goff = np_oracle.filterinterp_defor_bwd(variant, img, flow, filt, off, gout)
+    assert np.abs(gimg - n_gimg).max() <= 2e-4 and np.abs(gflow - n_gflow).max() <= 2e-4
+    assert np.abs(goff - n_goff).max() <= 2e-4
+    valid = np_oracle._fi_geometry(flow, H, W, fs)[0]
+    gv = np.where(valid[:, None], gout, 0).astype(f32)
+    if variant == 2:
+        assert gfilt is None
+    else:
+        assert np.abs(gfilt - n_gfilt).max() <= 2e-4
+        # 2. the forward is linear in the filter: <gout, F(filt = d)> == <gfilt, d>
+        d = rng.normal(size=filt.shape).astype(f32)
+        lin = np.where(valid[:, None], oracle.filterinterp_defor_fwd(variant, img, flow, d, off), 0)
+        if not (variant == 0 and fs not in (4, 6)):          # that forward has no body for other sizes
+            assert abs(_dot(gv, lin) - _dot(gfilt, d)) <= 2e-3
+    # 3. the offset gradient is the derivative of the forward where nothing switches
+    #    (quadrant membership and integer parts stay put): central differences on a few entries
+    if not (variant == 0 and fs not in (4, 6)):
+        eps = 1e-3
+        checked = 0
+        for _ in range(200):
+            b, k, y, x = rng.integers(B), rng.integers(2 * fs * fs), rng.integers(2, H - 2), rng.integers(2, W - 2)
+            if not valid[b, y, x]:
+                continue
+            op, om = off.copy(), off.copy()
+            op[b, k, y, x] += eps
+            om[b, k, y, x] -= eps
+            fp = oracle.filterinterp_defor_fwd(variant, img, flow, filt, op)[b, :, y, x].astype(np.float64)
+            fm = oracle.filterinterp_defor_fwd(variant, img, flow, filt, om)[b, :, y, x].astype(np.float64)
+            f0 = oracle.filterinterp_defor_fwd(variant, img, flow, filt, off)[b, :, y, x].astype(np.float64)
+            num = float(np.dot(gout[b, :, y, x], (fp - fm) / (2 * eps)))
+            # skip entries where the +-eps steps are not collinear (a tap changed quadrant / cell)
+            if np.abs((fp - f0) - (f0 - fm)).max() > 1e-4:
+                continue
+            assert abs(num - goff[b, k, y, x]) <= 5e-3 * max(1.0, abs(num)), (variant, b, k, y, x, num, goff[b, k, y, x])
+            checked += 1
+        assert checked >= 20
+
+
 def test_projection_backward_closed_form(oracle, np_oracle):
     rng = np.random.default_rng(12)
     B, H, W = 2, 12, 16
@@ -340,6 +390,8 @@ def test_golden_fixtures_reproduced(oracle, golden_dir):
         assert np.array_equal(got, g[name])
     for v, name in ((0, "offset"), (1, "region"), (2, "nofilter")):
         assert np.array_equal(oracle.filterinterp_defor_fwd(v, img, flow, filt, off), g["fi_out_" + name])
+        for got, n in zip(oracle.filterinterp_defor_bwd(v, img, flow, filt, off, gout), ("gimg", "gflow", "gfilt", "goff")):
+            assert (got is None and v == 2) or np.array_equal(got, g["fi_%s_%s" % (n, name)])
     assert np.array_equal(oracle.filterinterp_ori_fwd(img[:1], flow[:1], g["fi5_filt"]), g["fi5_out"])
     # the two copy-through pixels planted by the generator
     assert np.array_equal(g["fi_out"][0, :, 5, 7], img[0, :, 5, 7])

@@ -30,6 +30,8 @@ SIGNATURES = {
     "vfi_filterinterp_backward_ori": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_forward_defor": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
                                        Strides, _p],
+    "vfi_filterinterp_backward_defor": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides,
+                                        Strides, Strides, _p],
     "vfi_flowprojection_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
     "vfi_flowprojection_backward": [_p, _p, _p, _p, _i, _i, _i, Strides, Strides, _p],
     "vfi_depthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
@@ -157,6 +159,32 @@ def filterinterp_forward_defor(variant, input1, input2, input3, input4, output):
         return _finish(lib().vfi_filterinterp_forward_defor(
             variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(output), b, c, h, w, fs, _st(input1),
             _st(input2), _st(input3), s4, _stream(input1)))
+
+
+def filterinterp_backward_defor(variant, input1, input2, input3, input4, gradoutput, gradinput1, gradinput2,
+                                gradinput3, gradinput4):
+    """Backward of the deformable variants; variant DEFOR_NOFILTER: input4 = gradinput4 = None."""
+    dims = _fi_checks(input1, input2, input3, gradinput1)
+    if dims is None:
+        return 1
+    if input2.stride(0) != gradinput2.stride(0) or input2.stride(1) != gradinput2.stride(1):
+        return 1
+    if input3.stride(1) != gradinput3.stride(1):
+        return 1
+    b, c, h, w = dims
+    if variant == DEFOR_NOFILTER:
+        fs = int(math.sqrt(input3.size(1) // 2))
+        p4, g4, s4 = ctypes.c_void_p(0), ctypes.c_void_p(0), _st(input3)
+    else:
+        if input4.stride(3) != 1:
+            return 1
+        fs = int(math.sqrt(input3.size(1)))
+        p4, g4, s4 = _ptr(input4), _ptr(gradinput4), _st(input4)
+    with torch.cuda.device(_dev(input1)):
+        return _finish(lib().vfi_filterinterp_backward_defor(
+            variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(gradoutput), _ptr(gradinput1),
+            _ptr(gradinput2), _ptr(gradinput3), g4, b, c, h, w, fs, _st(input1), _st(input2), _st(input3), s4,
+            _stream(input1)))
 
 
 # ---------------------------------------------------------------- flowprojection_cuda / depthflowprojection_cuda

@@ -259,6 +259,116 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_defor(
     }
 }
 
+// ------------------------------------------------------------------ backward, deformable variants
+
+// filterinterpolation_cuda_kernel.cu:430-1215 (VARIANT 0), :1500-1935 (1), :2195-2567 (2).  Per valid
+// pixel and tap: quadrant weight by integer index (0) or displaced position (1, 2); image gradient
+// scattered to the clamped UNDISPLACED tap (the reference's own approximation) with atomics; filter
+// and offset-field gradients belong to this pixel alone (plain read-modify-write, the same values as
+// the reference's atomicAdd); flow gradient from the forward's quadrant sums.
+template <int VARIANT>
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    const float* __restrict__ in4, const float* __restrict__ gout, float* g1, float* g2, float* g3, float* g4,
+    int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    if (!fi_valid(fx, fy, x2, y2, w, h)) return;
+    const int fs2 = fs * fs;
+    const int ix = (int)x2, iy = (int)y2;
+    const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    const float* img = in1 + (int64_t)b * s1.b;
+    float* gimg = g1 + (int64_t)b * s1.b;
+    const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    // VARIANT 2: the third input IS the offset field and g3 its gradient; no filter
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    float* gfpx = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    const float* opx = (VARIANT == VFI_DEFOR_NOFILTER) ? fpx : in4 + (int64_t)b * s4.b + (int64_t)y * s4.h + x;
+    float* gopx = (VARIANT == VFI_DEFOR_NOFILTER) ? gfpx : g4 + (int64_t)b * s4.b + (int64_t)y * s4.h + x;
+    const int64_t ocs = (VARIANT == VFI_DEFOR_NOFILTER) ? s3.c : s4.c;
+    const float kq[4] = { (1.0f - alpha) * (1.0f - beta), alpha * (1.0f - beta), (1.0f - alpha) * beta, alpha * beta };
+    float gx = 0.0f, gy = 0.0f;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = img + (int64_t)c * s1.c;
+        float* gp = gimg + (int64_t)c * s1.c;
+        const float g = gpx[(int64_t)c * s1.c];
+        const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
+                              g * (1.0f - alpha) * beta,          g * alpha * beta };
+        float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int dj = 0; dj < fs; ++dj) {
+            const int j = T + dj, cj = clampi(j, 0, h - 1);
+            for (int di = 0; di < fs; ++di) {
+                const int i = L + di, ci = clampi(i, 0, w - 1);
+                const int k = dj * fs + di;
+                const float fracY = (float)cj + opx[(int64_t)k * ocs];
+                const float fracX = (float)ci + opx[(int64_t)(fs2 + k) * ocs];
+                int quad;
+                if constexpr (VARIANT == VFI_DEFOR_OFFSET) quad = (j > iy ? 2 : 0) + (i > ix ? 1 : 0);
+                else if (fracX <= x2 && fracY <= y2) quad = 0;
+                else if (fracX > x2 && fracY <= y2) quad = 1;
+                else if (fracX <= x2 && fracY > y2) quad = 2;
+                else if (fracX > x2 && fracY > y2) quad = 3;
+                else continue;                                      // NaN position: no quadrant
+                const int Top = (int)fracY, Left = (int)fracX;
+                const float phiY = fracY - (float)Top, phiX = fracX - (float)Left;
+                const int64_t t = (int64_t)clampi(Top, 0, h - 1) * s1.h, bo = (int64_t)clampi(Top + 1, 0, h - 1) * s1.h;
+                const int l = clampi(Left, 0, w - 1), r = clampi(Left + 1, 0, w - 1);
+                const float vTL = p[t + l], vTR = p[t + r], vBL = p[bo + l], vBR = p[bo + r];
+                float v = ((1.0f - phiX) * (1.0f - phiY)) * vTL;
+                v = fmaf(phiX * (1.0f - phiY), vTR, v);
+                v = fmaf((1.0f - phiX) * phiY, vBL, v);
+                v = fmaf(phiY * phiX, vBR, v);
+                float dY = (-(1.0f - phiX)) * vTL;
+                dY = fmaf(1.0f - phiX, vBL, dY);
+                dY = fmaf(-phiX, vTR, dY);
+                dY = fmaf(phiX, vBR, dY);
+                float dX = (-(1.0f - phiY)) * vTL;
+                dX = fmaf(1.0f - phiY, vTR, dX);
+                dX = fmaf(-phiY, vBL, dX);
+                dX = fmaf(phiY, vBR, dX);
+                const int64_t o = (int64_t)cj * s1.h + ci;
+                if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
+                    atomicAdd(&gp[o], qg[quad]);
+                    q[quad] = q[quad] + v;
+                    gopx[(int64_t)k * ocs] += g * kq[quad] * dY;
+                    gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX;
+                } else {
+                    const float wgt = fpx[(int64_t)k * s3.c];
+                    atomicAdd(&gp[o], qg[quad] * wgt);
+                    gfpx[(int64_t)k * s3.c] += qg[quad] * v;
+                    q[quad] = fmaf(v, wgt, q[quad]);
+                    gopx[(int64_t)k * ocs] += g * kq[quad] * dY * wgt;
+                    gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX * wgt;
+                }
+            }
+        }
+        {
+            const float gamma = 1.0f - beta;
+            float temp = gamma * (q[1] - q[0]);
+            temp = fmaf(1.0f - gamma, q[3] - q[2], temp);
+            gx = fmaf(g, temp, gx);
+        }
+        {
+            const float gamma = 1.0f - alpha;
+            float temp = gamma * (q[2] - q[0]);
+            temp = fmaf(1.0f - gamma, q[3] - q[1], temp);
+            gy = fmaf(g, temp, gy);
+        }
+    }
+    float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    gf[0] = gx;
+    gf[s2.c] = gy;
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -343,6 +453,39 @@ extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, 
     case VFI_DEFOR_NOFILTER:
         hipLaunchKernelGGL(fi_forward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3,
                            input3, output, channel, h, w, filter_size, s1, s2, s3, s3);
+        break;
+    default:
+        return VFI_ERR_SHAPE;
+    }
+    return launch_status();
+}
+
+extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1, const float* input2,
+                                                const float* input3, const float* input4, const float* gradoutput,
+                                                float* gradinput1, float* gradinput2, float* gradinput3,
+                                                float* gradinput4, int batch, int channel, int h, int w,
+                                                int filter_size, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                                vfi_strides s4, vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_size <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3) return VFI_ERR_SHAPE;
+    if (variant != VFI_DEFOR_NOFILTER && (!input4 || !gradinput4)) return VFI_ERR_SHAPE;
+    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+    case VFI_DEFOR_OFFSET:
+        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
+                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           s1, s2, s3, s4);
+        break;
+    case VFI_DEFOR_REGION:
+        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
+                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           s1, s2, s3, s4);
+        break;
+    case VFI_DEFOR_NOFILTER:
+        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3, input3,
+                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
+                           s1, s2, s3, s3);
         break;
     default:
         return VFI_ERR_SHAPE;

@@ -136,6 +136,72 @@ int FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv(at::Tensor& input
                                                  st(input2), st(input3), st(input3), s.stream));
 }
 
+// filterinterpolation_cuda.cc:93-187 (variant 0) and :273-367 (variant 1)
+int defor4_bwd(int variant, at::Tensor& input1, at::Tensor& input2, at::Tensor& input3, at::Tensor& input4,
+               at::Tensor& gradoutput, at::Tensor& gradinput1, at::Tensor& gradinput2, at::Tensor& gradinput3,
+               at::Tensor& gradinput4) {
+    const int error = 1;
+    const int channel = input1.size(1), batch = input1.size(0);
+    if (input2.size(0) != batch) return error;
+    if (input2.size(1) != 2) return error;
+    const int h = input1.size(2), w = input1.size(3);
+    if (input2.size(2) != h) return error;
+    if (input2.size(3) != w) return error;
+    const int filter_size = (int)std::sqrt((float)input3.size(1));
+    if (input1.stride(3) != 1 || input2.stride(3) != 1 || input3.stride(3) != 1 || input4.stride(3) != 1)
+        return error;
+    if (input1.stride(0) != gradinput1.stride(0)) return error;
+    if (input2.stride(0) != gradinput2.stride(0)) return error;
+    if (input1.stride(1) != gradinput1.stride(1)) return error;
+    if (input2.stride(1) != gradinput2.stride(1)) return error;
+    if (input3.stride(1) != gradinput3.stride(1)) return error;
+    StreamScope s(input1);
+    return finish(vfi_filterinterp_backward_defor(variant, cptr(input1), cptr(input2), cptr(input3), cptr(input4),
+                                                  cptr(gradoutput), mptr(gradinput1), mptr(gradinput2),
+                                                  mptr(gradinput3), mptr(gradinput4), batch, channel, h, w,
+                                                  filter_size, st(input1), st(input2), st(input3), st(input4),
+                                                  s.stream));
+}
+int FilterInterpolationLayer_gpu_backward(at::Tensor& input1, at::Tensor& input2, at::Tensor& input3,
+                                          at::Tensor& input4, at::Tensor& gradoutput, at::Tensor& gradinput1,
+                                          at::Tensor& gradinput2, at::Tensor& gradinput3, at::Tensor& gradinput4) {
+    return defor4_bwd(VFI_DEFOR_OFFSET, input1, input2, input3, input4, gradoutput, gradinput1, gradinput2,
+                      gradinput3, gradinput4);
+}
+int FilterInterpolationLayer_gpu_backward_deforconv(at::Tensor& input1, at::Tensor& input2, at::Tensor& input3,
+                                                    at::Tensor& input4, at::Tensor& gradoutput,
+                                                    at::Tensor& gradinput1, at::Tensor& gradinput2,
+                                                    at::Tensor& gradinput3, at::Tensor& gradinput4) {
+    return defor4_bwd(VFI_DEFOR_REGION, input1, input2, input3, input4, gradoutput, gradinput1, gradinput2,
+                      gradinput3, gradinput4);
+}
+
+// filterinterpolation_cuda.cc:448-533
+int FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv(at::Tensor& input1, at::Tensor& input2,
+                                                                at::Tensor& input3, at::Tensor& gradoutput,
+                                                                at::Tensor& gradinput1, at::Tensor& gradinput2,
+                                                                at::Tensor& gradinput3) {
+    const int error = 1;
+    const int channel = input1.size(1), batch = input1.size(0);
+    if (input2.size(0) != batch) return error;
+    if (input2.size(1) != 2) return error;
+    const int h = input1.size(2), w = input1.size(3);
+    if (input2.size(2) != h) return error;
+    if (input2.size(3) != w) return error;
+    const int filter_size = (int)std::sqrt((float)(input3.size(1) / 2));
+    if (input1.stride(3) != 1 || input2.stride(3) != 1 || input3.stride(3) != 1) return error;
+    if (input1.stride(0) != gradinput1.stride(0)) return error;
+    if (input2.stride(0) != gradinput2.stride(0)) return error;
+    if (input1.stride(1) != gradinput1.stride(1)) return error;
+    if (input2.stride(1) != gradinput2.stride(1)) return error;
+    if (input3.stride(1) != gradinput3.stride(1)) return error;
+    StreamScope s(input1);
+    return finish(vfi_filterinterp_backward_defor(VFI_DEFOR_NOFILTER, cptr(input1), cptr(input2), cptr(input3),
+                                                  nullptr, cptr(gradoutput), mptr(gradinput1), mptr(gradinput2),
+                                                  mptr(gradinput3), nullptr, batch, channel, h, w, filter_size,
+                                                  st(input1), st(input2), st(input3), st(input3), s.stream));
+}
+
 // ---------------------------------------------------------------- flowprojection_cuda
 
 // flowprojection_cuda.cc:9-57
@@ -401,6 +467,9 @@ PYBIND11_MODULE(filterinterpolation_cuda, m) {
     m.def("FilterInterpolationLayer_gpu_forward", &FilterInterpolationLayer_gpu_forward, "FilterInterpolation forward (HIP, gfx950)");
     m.def("FilterInterpolationLayer_gpu_forward_deforconv", &FilterInterpolationLayer_gpu_forward_deforconv, "FilterInterpolation forward deforconv (HIP, gfx950)");
     m.def("FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv", &FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv, "FilterInterpolation forward no filter with deforconv (HIP, gfx950)");
+    m.def("FilterInterpolationLayer_gpu_backward", &FilterInterpolationLayer_gpu_backward, "FilterInterpolation backward (HIP, gfx950)");
+    m.def("FilterInterpolationLayer_gpu_backward_deforconv", &FilterInterpolationLayer_gpu_backward_deforconv, "FilterInterpolation backward deforconv (HIP, gfx950)");
+    m.def("FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv", &FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv, "FilterInterpolation backward no filter with deforconv (HIP, gfx950)");
 }
 PYBIND11_MODULE(flowprojection_cuda, m) {
     m.def("FlowProjectionLayer_gpu_forward", &FlowProjectionLayer_gpu_forward, "FlowProjection forward (HIP, gfx950)");

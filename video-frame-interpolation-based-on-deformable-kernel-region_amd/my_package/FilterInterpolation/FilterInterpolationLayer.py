@@ -1,8 +1,8 @@
 """Mirror of my_package/FilterInterpolation/FilterInterpolationLayer.py:10-92 (reference).
 
 The shipped reference calls the `_ori` kernels (FilterInterpolationLayer.py:35, 73);
-the three deformable-kernel forwards it keeps commented out (:36-38) are exposed
-here as separate Functions so they can be used and tested."""
+the three deformable-kernel variants it keeps commented out (:36-38, :74-76) are
+exposed here as separate Functions so they can be used and tested."""
 import torch
 from torch.autograd import Function
 
@@ -40,14 +40,14 @@ class FilterInterpolationLayer(Function):
         return gradinput1, gradinput2, gradinput3
 
 
-class _DeformableForward(Function):
-    """Forward-only wrappers of the deformable-kernel variants (no backward kernels yet)."""
+class _Deformable(Function):
+    """The deformable-kernel variants (forward and backward)."""
     variant = None
 
     @classmethod
-    def _run(cls, input1, input2, input3, input4):
+    def _fwd(cls, ctx, input1, input2, input3, input4):
         require_gpu(input1, input2, input3)
-        # 4-input forward leaves the caller's zeros for filter sizes other than 4 and 6
+        # the 4-input forward leaves the caller's zeros for filter sizes other than 4 and 6
         output = torch.zeros_like(input1)
         if cls.variant == "offset":
             err = my_lib.FilterInterpolationLayer_gpu_forward(input1, input2, input3, input4, output)
@@ -57,34 +57,65 @@ class _DeformableForward(Function):
             err = my_lib.FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv(input1, input2, input3, output)
         if err != 0:
             print(err)
+        if input4 is None:
+            ctx.save_for_backward(input1, input2, input3)
+        else:
+            ctx.save_for_backward(input1, input2, input3, input4)
         return output
 
+    @classmethod
+    def _bwd(cls, ctx, gradoutput):
+        gradoutput = gradoutput.contiguous()
+        saved = ctx.saved_tensors
+        grads = [torch.zeros_like(t) for t in saved]
+        if cls.variant == "offset":
+            err = my_lib.FilterInterpolationLayer_gpu_backward(*saved, gradoutput, *grads)
+        elif cls.variant == "deforconv":
+            err = my_lib.FilterInterpolationLayer_gpu_backward_deforconv(*saved, gradoutput, *grads)
+        else:
+            err = my_lib.FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv(*saved, gradoutput, *grads)
+        if err != 0:
+            print(err)
+        return tuple(grads)
 
-class FilterInterpolationOffsetLayer(_DeformableForward):
-    """FilterInterpolationLayer_gpu_forward (reference FilterInterpolationLayer.py:36)."""
+
+class FilterInterpolationOffsetLayer(_Deformable):
+    """FilterInterpolationLayer_gpu_forward / _backward (reference FilterInterpolationLayer.py:36, :74)."""
     variant = "offset"
 
     @staticmethod
     def forward(ctx, input1, input2, input3, input4):
-        return FilterInterpolationOffsetLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
+        return FilterInterpolationOffsetLayer._fwd(ctx, input1.contiguous(), input2.contiguous(), input3.contiguous(),
                                                    input4.contiguous())
 
+    @staticmethod
+    def backward(ctx, gradoutput):
+        return FilterInterpolationOffsetLayer._bwd(ctx, gradoutput)
 
-class FilterInterpolationDeforConvLayer(_DeformableForward):
-    """FilterInterpolationLayer_gpu_forward_deforconv (reference FilterInterpolationLayer.py:37)."""
+
+class FilterInterpolationDeforConvLayer(_Deformable):
+    """FilterInterpolationLayer_gpu_forward_deforconv / _backward_deforconv (reference :37, :75)."""
     variant = "deforconv"
 
     @staticmethod
     def forward(ctx, input1, input2, input3, input4):
-        return FilterInterpolationDeforConvLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
-                                                      input4.contiguous())
+        return FilterInterpolationDeforConvLayer._fwd(ctx, input1.contiguous(), input2.contiguous(),
+                                                      input3.contiguous(), input4.contiguous())
+
+    @staticmethod
+    def backward(ctx, gradoutput):
+        return FilterInterpolationDeforConvLayer._bwd(ctx, gradoutput)
 
 
-class FilterInterpolationNoFilterLayer(_DeformableForward):
-    """FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv (reference FilterInterpolationLayer.py:38)."""
+class FilterInterpolationNoFilterLayer(_Deformable):
+    """FilterInterpolationLayer_gpu_forward_nofilterwithdeforconv / _backward_... (reference :38, :76)."""
     variant = "nofilter"
 
     @staticmethod
     def forward(ctx, input1, input2, input3):
-        return FilterInterpolationNoFilterLayer._run(input1.contiguous(), input2.contiguous(), input3.contiguous(),
-                                                     None)
+        return FilterInterpolationNoFilterLayer._fwd(ctx, input1.contiguous(), input2.contiguous(),
+                                                     input3.contiguous(), None)
+
+    @staticmethod
+    def backward(ctx, gradoutput):
+        return FilterInterpolationNoFilterLayer._bwd(ctx, gradoutput)
