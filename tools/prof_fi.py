@@ -13,6 +13,9 @@ from vfidkr_amd import cabi, synthetic as S  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "smooth"
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 196
+if len(sys.argv) > 3:        # development knobs of the LDS kernel (flags[:groups])
+    fl = sys.argv[3].split(":")
+    cabi.lib().vfi_debug_filterinterp(int(fl[0], 0), int(fl[1], 0) if len(fl) > 1 else 0)
 dev = torch.device("cuda:0")
 h, w = S.padded_size(1080, 1920)
 gen = S.generator()
