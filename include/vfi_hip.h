@@ -189,6 +189,67 @@ int vfi_correlation_backward(const float* input1, const float* input2, const flo
                              int stride1, int stride2,
                              vfi_stream_t stream);
 
+/* ==== glue either side of the ops above: the reference does these with torch
+ * built-ins and Python; here each is one launch.  No reference binding exists for them: the
+ * host-side mirrors are <pkg>/fused.py. ========================================================= */
+
+/* forward_flownets (networks/DAIN_slowmotion.py:204-216, DAIN.py:296-311):
+ * output[B,C,4hq,4wq] = nn.Upsample(scale_factor=4, mode='bilinear')((mul0 * input) * mul1),
+ * torch's align_corners=False rule.  mul0 = div_flow, mul1 = the time offset. */
+int vfi_flow_upsample4(const float* input, float* output,
+                       int batch, int channels, int hq, int wq, float mul0, float mul1,
+                       vfi_strides sq, vfi_strides so,
+                       vfi_stream_t stream);
+
+/* the same upsample fused into (Depth)FlowProjection: the splat reads the quarter-resolution flow
+ * [B,2,hq,wq] and forms each source pixel's flow on the fly; count [B,1,4hq,4wq] and output
+ * [B,2,4hq,4wq] as vfi_flowprojection_forward.  Results equal vfi_flow_upsample4 followed by the
+ * unfused projection bit for bit. */
+int vfi_flowprojection_forward_up4(const float* flow_q, float* count, float* output,
+                                   int batch, int hq, int wq, float mul0, float mul1, int fillhole,
+                                   vfi_strides sq, vfi_strides sc, vfi_strides so,
+                                   vfi_stream_t stream);
+int vfi_depthflowprojection_forward_up4(const float* flow_q, const float* input2,
+                                        float* count, float* output,
+                                        int batch, int hq, int wq, float mul0, float mul1, int fillhole,
+                                        vfi_strides sq, vfi_strides s2, vfi_strides sc, vfi_strides so,
+                                        vfi_stream_t stream);
+
+/* FilterInterpolate (networks/DAIN_slowmotion.py:324-335, DAIN.py:560-573): out0 = A1(ref0, flow0,
+ * filt0), out2 = A1(ref2, flow2, filt2), blend = out0 * w0 + out2 * w2 (products rounded
+ * separately, as torch's three elementwise ops).  out0 / out2 may be NULL.  ref0/ref2, flow0/flow2
+ * and filt0/filt2 share strides pairwise; blend/out0/out2 share s_out. */
+int vfi_filterinterp_blend_forward(const float* ref0, const float* ref2,
+                                   const float* flow0, const float* flow2,
+                                   const float* filt0, const float* filt2,
+                                   float* blend, float* out0, float* out2,
+                                   int batch, int channel, int h, int w, int filter_channels,
+                                   float w0, float w2,
+                                   vfi_strides s_ref, vfi_strides s_flow, vfi_strides s_filt, vfi_strides s_out,
+                                   vfi_stream_t stream);
+
+/* PWCDCNet.warp (PWCNet/PWCNet.py:159-199): output = grid_sample(x, grid(flow)) * mask, mask = 1
+ * where grid_sample(ones, grid) >= 0.9999 else 0; bilinear, zeros padding.  align_corners: 1 = the
+ * grid_sample of torch <= 1.2 the reference was written for, 0 = the default of torch >= 1.3. */
+int vfi_pwc_warp_forward(const float* x, const float* flow, float* output,
+                         int batch, int channel, int h, int w, int align_corners,
+                         vfi_strides sx, vfi_strides sf, vfi_strides so,
+                         vfi_stream_t stream);
+
+/* frame boundary (demo_MiddleBury.py:280-318, 350-364, 370-388).
+ * u8 -> planar: dst[b,c,y,x] = src[b, clamp(y - pad_top), clamp(x - pad_left), c] / 255 for the padded
+ * frame (h + pad_top + pad_bottom) x (w + pad_left + pad_right); src is dense [B,h,w,3] uint8.
+ * planar -> u8: dst[b,y,x,c] = uint8(rint(255 * clip(src[b,c,top+y,left+x], 0, 1))), dst dense [B,h,w,3].
+ * error sums: sums[0] += sum|a-b|, sums[1] += sum (a-b)^2 over n bytes (exact; caller zeroes sums). */
+int vfi_frame_u8_to_planar(const unsigned char* src_hwc, float* dst,
+                           int batch, int h, int w, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                           vfi_strides sd, vfi_stream_t stream);
+int vfi_planar_to_frame_u8(const float* src, unsigned char* dst_hwc,
+                           int batch, int h, int w, int top, int left,
+                           vfi_strides ss, vfi_stream_t stream);
+int vfi_frame_error_sums(const unsigned char* a, const unsigned char* b, int64_t n,
+                         unsigned long long* sums, vfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

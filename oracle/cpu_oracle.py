@@ -230,3 +230,57 @@ def correlation_bwd(f1, f2, gout, pad=4, k=1, md=4, s1=1, s2=1):
     _check(lib().vfi_oracle_correlation_bwd(_p(f1), _p(f2), _p(gout), _p(g1), _p(g2), B, C, H, W, pad, k, md, s1,
                                             s2), "correlation_bwd")
     return g1, g2
+
+
+# ---------------------------------------------------------------- glue either side of the ops
+
+def flow_upsample4(x, m0, m1, fmad=0):
+    x = _f32(x)
+    B, C, hq, wq = x.shape
+    out = np.zeros((B, C, 4 * hq, 4 * wq), np.float32)
+    _check(lib().vfi_oracle_flow_upsample4(_p(x), _p(out), B, C, hq, wq, ctypes.c_float(m0), ctypes.c_float(m1),
+                                           int(fmad)), "flow_upsample4")
+    return out
+
+
+def flowproj_up4_fwd(flow_q, m0, m1, fillhole=1, depth=None, fmad=1):
+    """forward_flownets + FlowProject: the composition the fused GPU entry points compute."""
+    flow = flow_upsample4(flow_q, m0, m1, fmad)
+    return flowproj_fwd(flow, fillhole) if depth is None else depthflowproj_fwd(flow, depth, fillhole)
+
+
+def filterinterp_blend(ref0, ref2, flow0, flow2, filt0, filt2, w0, w2, fmad=0):
+    """DAIN.FilterInterpolate: (out0 * w0 + out2 * w2, out0, out2), float32 throughout."""
+    out0 = filterinterp_ori_fwd(ref0, flow0, filt0, fmad)
+    out2 = filterinterp_ori_fwd(ref2, flow2, filt2, fmad)
+    return out0 * np.float32(w0) + out2 * np.float32(w2), out0, out2
+
+
+def pwc_warp(x, flo, align_corners=True, fmad=0):
+    x, flo = _f32(x), _f32(flo)
+    B, C, H, W = x.shape
+    out = np.zeros_like(x)
+    _check(lib().vfi_oracle_pwc_warp(_p(x), _p(flo), _p(out), B, C, H, W, int(bool(align_corners)), int(fmad)),
+           "pwc_warp")
+    return out
+
+
+def frame_to_padded(frames_u8, left, right, top, bottom):
+    """demo_MiddleBury.py:280-318: transpose, astype(float32) / 255.0, ReplicationPad2d."""
+    x = np.transpose(frames_u8, (0, 3, 1, 2)).astype("float32") / 255.0
+    return np.pad(x, ((0, 0), (0, 0), (top, bottom), (left, right)), mode="edge")
+
+
+def padded_to_frame(y, height, width, left, top):
+    """demo_MiddleBury.py:350-364: 255.0 * y.clip(0, 1.0) cropped, transposed, np.round, uint8."""
+    v = np.transpose(255.0 * y.clip(0, 1.0)[:, :, top:top + height, left:left + width], (0, 2, 3, 1))
+    return np.round(v).astype(np.uint8)
+
+
+def frame_error(rec_u8, gt_u8):
+    """demo_MiddleBury.py:370-381: (mean |diff|, PSNR)."""
+    import math
+    diff = 128.0 + rec_u8 - gt_u8
+    err = float(np.mean(np.abs(diff - 128.0)))
+    mse = float(np.mean((diff - 128.0) ** 2))
+    return err, (float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse)))

@@ -933,3 +933,85 @@ int vfi_oracle_correlation_bwd(const float* f1, const float* f2, const float* go
     }
     return 0;
 }
+
+/* ------------------------------------------------------------ glue */
+
+/* ATen area_pixel_compute_source_index, align_corners=False, scale 1/4: 0.25*(dst+0.5)-0.5 clamped
+ * at 0; second tap one further unless at the last input index (UpSampleBilinear2d) */
+static inline void up4_tap(int dst, int in_size, int* i0, int* i1, float* l0, float* l1) {
+    float src = 0.25f * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    *i0 = (int)src;
+    *i1 = *i0 + (*i0 < in_size - 1 ? 1 : 0);
+    *l1 = src - (float)*i0;
+    *l0 = 1.0f - *l1;
+}
+
+int vfi_oracle_flow_upsample4(const float* in, float* out, int B, int C, int hq, int wq,
+                              float m0, float m1, int fmad) {
+    if (B <= 0 || C <= 0 || hq <= 0 || wq <= 0) return 1;
+    const int H = 4 * hq, W = 4 * wq;
+    for (int bc = 0; bc < B * C; ++bc) {
+        const float* p = in + (i64)bc * hq * wq;
+        float* o = out + (i64)bc * H * W;
+        for (int y = 0; y < H; ++y) {
+            int y0, y1; float ly0, ly1;
+            up4_tap(y, hq, &y0, &y1, &ly0, &ly1);
+            for (int x = 0; x < W; ++x) {
+                int x0, x1; float lx0, lx1;
+                up4_tap(x, wq, &x0, &x1, &lx0, &lx1);
+                /* div_flow * temp * time_offset: two float32 products, left to right */
+                const float p00 = (m0 * p[(i64)y0 * wq + x0]) * m1, p01 = (m0 * p[(i64)y0 * wq + x1]) * m1;
+                const float p10 = (m0 * p[(i64)y1 * wq + x0]) * m1, p11 = (m0 * p[(i64)y1 * wq + x1]) * m1;
+                /* h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11) */
+                const float t0 = mac(lx1, p01, lx0 * p00, fmad);
+                const float t1 = mac(lx1, p11, lx0 * p10, fmad);
+                o[(i64)y * W + x] = mac(ly1, t1, ly0 * t0, fmad);
+            }
+        }
+    }
+    return 0;
+}
+
+int vfi_oracle_pwc_warp(const float* x, const float* flo, float* out, int B, int C, int H, int W,
+                        int align_corners, int fmad) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
+    const i64 HW = (i64)H * W;
+    for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+    for (int xx = 0; xx < W; ++xx) {
+        const i64 px = (i64)y * W + xx;
+        /* vgrid = grid + flo; 2.0*v/max(W-1,1) - 1.0   (PWCNet.py:181-185) */
+        const float vx = (float)xx + flo[((i64)b * 2 + 0) * HW + px];
+        const float vy = (float)y + flo[((i64)b * 2 + 1) * HW + px];
+        const float gx = 2.0f * vx / (float)maxi(W - 1, 1) - 1.0f;
+        const float gy = 2.0f * vy / (float)maxi(H - 1, 1) - 1.0f;
+        /* ATen grid_sampler_unnormalize */
+        const float ix = align_corners ? ((gx + 1.0f) / 2.0f) * (float)(W - 1) : ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        const float iy = align_corners ? ((gy + 1.0f) / 2.0f) * (float)(H - 1) : ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float wnw = (fx0 + 1.0f - ix) * (fy0 + 1.0f - iy), wne = (ix - fx0) * (fy0 + 1.0f - iy);
+        const float wsw = (fx0 + 1.0f - ix) * (iy - fy0), wse = (ix - fx0) * (iy - fy0);
+        const int finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
+        const int inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const int iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
+        /* grid_sample of the ones tensor, then mask[mask<0.9999]=0; mask[mask>0]=1 */
+        float m = 0.0f;
+        if (iny0 && inx0) m += wnw;
+        if (iny0 && inx1) m += wne;
+        if (iny1 && inx0) m += wsw;
+        if (iny1 && inx1) m += wse;
+        const float mask = (m < 0.9999f) ? 0.0f : (m > 0.0f ? 1.0f : m);
+        for (int c = 0; c < C; ++c) {
+            const float* p = x + ((i64)b * C + c) * HW;
+            float v = 0.0f;
+            if (iny0 && inx0) v = mac(p[(i64)y0 * W + x0], wnw, v, fmad);
+            if (iny0 && inx1) v = mac(p[(i64)y0 * W + x0 + 1], wne, v, fmad);
+            if (iny1 && inx0) v = mac(p[(i64)(y0 + 1) * W + x0], wsw, v, fmad);
+            if (iny1 && inx1) v = mac(p[(i64)(y0 + 1) * W + x0 + 1], wse, v, fmad);
+            out[((i64)b * C + c) * HW + px] = v * mask;
+        }
+    }
+    return 0;
+}

@@ -104,6 +104,18 @@ int vfi_oracle_correlation_bwd(const float* f1, const float* f2, const float* go
                                float* g1, float* g2, int B, int C, int H, int W,
                                int pad, int k, int md, int s1, int s2);
 
+/* ---- glue either side of the ops.  These restate torch built-ins the reference
+ * calls (third-party: ATen of torch 1.0-1.4; restated from ATen's UpSampleBilinear2d and GridSampler
+ * kernels) and are pinned against the torch CPU build of this image in tests/test_oracle.py. */
+
+/* nn.Upsample(scale_factor=4, mode='bilinear') of (m0 * in) * m1, align_corners=False
+ * (networks/DAIN_slowmotion.py:213-215) */
+int vfi_oracle_flow_upsample4(const float* in, float* out, int B, int C, int hq, int wq,
+                              float m0, float m1, int fmad);
+/* PWCDCNet.warp (PWCNet/PWCNet.py:159-199) */
+int vfi_oracle_pwc_warp(const float* x, const float* flo, float* out, int B, int C, int H, int W,
+                        int align_corners, int fmad);
+
 #ifdef __cplusplus
 }
 #endif

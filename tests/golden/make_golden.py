@@ -106,6 +106,28 @@ def main():
     g["out_k3s2"] = o.correlation_fwd(f1, f2, 3, 3, 4, 1, 2, order=0)
     g["out_flownet"] = o.correlation_fwd(f1[:, :8], f2[:, :8], 20, 1, 20, 2, 2, order=0)
     np.savez_compressed(os.path.join(HERE, "correlation.npz"), **g)
+
+    # glue either side of the ops; its own generator, so the fixtures above keep their values
+    rng = np.random.default_rng(20250203)
+    g = {}
+    g["flow_q"] = (rng.normal(size=(2, 2, 6, 9)) * 0.1).astype(np.float32)       # x 20 x t: a few pixels
+    g["up4"] = o.flow_upsample4(g["flow_q"], 20.0, 0.25)
+    for fh in (0, 1):
+        g["proj_up4_fh%d" % fh], g["proj_up4_count_fh%d" % fh] = o.flowproj_up4_fwd(g["flow_q"], 20.0, 0.25, fh, fmad=0)
+    g["feat"] = rng.normal(size=(2, 4, 12, 17)).astype(np.float32)
+    g["flo"] = (rng.normal(size=(2, 2, 12, 17)) * 3).astype(np.float32)
+    for ac in (0, 1):
+        g["warp_ac%d" % ac] = o.pwc_warp(g["feat"], g["flo"], bool(ac))
+    g["ref0"], g["ref2"] = img[:1], img[1:]
+    g["flow0"], g["flow2"] = flow[:1], flow[1:]
+    g["filt0"], g["filt2"] = filt[:1], filt[1:]
+    g["blend"], g["blend_out0"], g["blend_out2"] = o.filterinterp_blend(g["ref0"], g["ref2"], g["flow0"], g["flow2"],
+                                                                         g["filt0"], g["filt2"], 0.75, 0.25)
+    g["frame_u8"] = rng.integers(0, 256, (2, 9, 14, 3), dtype=np.uint8)
+    g["frame_padded"] = o.frame_to_padded(g["frame_u8"], 3, 2, 4, 1)
+    g["frame_y"] = (g["frame_padded"] * 1.3 - 0.1).astype(np.float32)           # values below 0 and above 1 too
+    g["frame_back"] = o.padded_to_frame(g["frame_y"], 9, 14, 3, 4)
+    np.savez_compressed(os.path.join(HERE, "glue.npz"), **g)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -417,6 +417,160 @@ def test_correlation_backward(torch_mod, cabi, oracle):
         assert np.array_equal(cpu(g1), r1) and np.array_equal(cpu(g2), r2)
 
 
+# ------------------------------------------------------------------ glue either side of the ops
+
+@pytest.mark.parametrize("shape", [(1, 2, 8, 11), (2, 2, 5, 7), (1, 3, 1, 1), (1, 2, 18, 31)])
+def test_flow_upsample4_bit_exact(torch_mod, cabi, oracle, shape):
+    torch = torch_mod
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(size=shape).astype(f32)
+    B, C, hq, wq = shape
+    for m0, m1 in ((20.0, 0.5), (20.0, 0.25)):
+        out = torch.full((B, C, 4 * hq, 4 * wq), float("nan"), device="cuda:0")
+        assert cabi.flow_upsample4(gpu(torch, x), out, m0, m1) == 0
+        assert np.array_equal(cpu(out), oracle.flow_upsample4(x, m0, m1, fmad=1))
+    # into a channel slice of a larger tensor (zero-copy concat); nothing written outside it
+    big = torch.zeros((B, C + 3, 4 * hq, 4 * wq), device="cuda:0")
+    assert cabi.flow_upsample4(gpu(torch, x), big[:, 2:2 + C], 20.0, 0.5) == 0
+    assert np.array_equal(cpu(big[:, 2:2 + C]), oracle.flow_upsample4(x, 20.0, 0.5, fmad=1))
+    big[:, 2:2 + C] = 0
+    assert not big.any()
+    assert cabi.flow_upsample4(gpu(torch, x), torch.zeros((B, C, 4 * hq, 4 * wq + 1), device="cuda:0"), 1.0, 1.0) == 1
+
+
+@pytest.mark.parametrize("B,hq,wq", [(1, 8, 12), (2, 5, 18), (1, 1, 1), (1, 10, 50)])
+@pytest.mark.parametrize("fillhole", [0, 1])
+@pytest.mark.parametrize("depth", [False, True])
+def test_projection_from_quarter_flow(torch_mod, cabi, oracle, B, hq, wq, fillhole, depth):
+    """fused x4 upsample + splat == the unfused pair bit for bit; the pair agrees with the oracle as before."""
+    torch = torch_mod
+    rng = np.random.default_rng(hq * wq + B)
+    H, W = 4 * hq, 4 * wq
+    flow_q = gpu(torch, (rng.normal(size=(B, 2, hq, wq)) * 0.2).astype(f32))
+    dep_np = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    dep = gpu(torch, dep_np)
+    for m1 in (0.25, 0.5):
+        full = torch.empty((B, 2, H, W), device="cuda:0")
+        assert cabi.flow_upsample4(flow_q, full, 20.0, m1) == 0
+        c_ref = torch.full((B, 1, H, W), float("nan"), device="cuda:0")
+        o_ref = torch.full((B, 2, H, W), float("nan"), device="cuda:0")
+        c_fus, o_fus = torch.full_like(c_ref, float("nan")), torch.full_like(o_ref, float("nan"))
+        if depth:
+            assert cabi.depthflowprojection_forward(full, dep, c_ref, o_ref, fillhole) == 0
+            assert cabi.depthflowprojection_forward_up4(flow_q, dep, c_fus, o_fus, 20.0, m1, fillhole) == 0
+        else:
+            assert cabi.flowprojection_forward(full, c_ref, o_ref, fillhole) == 0
+            assert cabi.flowprojection_forward_up4(flow_q, c_fus, o_fus, 20.0, m1, fillhole) == 0
+        assert torch.equal(c_fus, c_ref) and torch.equal(o_fus, o_ref)
+        r_out, r_count = oracle.flowproj_up4_fwd(cpu(flow_q), 20.0, m1, fillhole, dep_np if depth else None, fmad=1)
+        if depth:
+            assert close(cpu(c_fus), r_count, 1e-4) and close(cpu(o_fus), r_out, 1e-4)
+        else:
+            assert np.array_equal(cpu(c_fus), r_count) and np.abs(cpu(o_fus) - r_out).max() <= 1e-4
+
+
+@pytest.mark.parametrize("B,C,H,W,fs", [(1, 3, 32, 48, 4), (2, 3, 17, 70, 4), (1, 2, 12, 20, 5), (1, 1, 1, 1, 4)])
+def test_filterinterp_blend(torch_mod, cabi, oracle, B, C, H, W, fs):
+    torch = torch_mod
+    rng = np.random.default_rng(B + C + H + W + fs)
+    ref0, ref2 = rng.random((B, C, H, W), dtype=f32), rng.random((B, C, H, W), dtype=f32)
+    flow0 = smooth_flow(rng, B, H, W, 2.0) if H > 1 else np.zeros((B, 2, H, W), f32)
+    flow2 = -flow0 + rng.uniform(-0.5, 0.5, flow0.shape).astype(f32)
+    flow0[0, 0, 0, 0] = W                                   # one copy-through pixel
+    filt0, filt2 = rng.random((B, fs * fs, H, W), dtype=f32), rng.random((B, fs * fs, H, W), dtype=f32)
+    for t in (0.5, 0.25, 0.125):
+        w0, w2 = float(1.0 - t), float(t)
+        blend = torch.full((B, C, H, W), float("nan"), device="cuda:0")
+        out0, out2 = torch.full_like(blend, float("nan")), torch.full_like(blend, float("nan"))
+        args = [gpu(torch, a) for a in (ref0, ref2, flow0, flow2, filt0, filt2)]
+        assert cabi.filterinterp_blend_forward(*args, blend, out0, out2, w0, w2) == 0
+        r_blend, r0, r2 = oracle.filterinterp_blend(ref0, ref2, flow0, flow2, filt0, filt2, w0, w2, fmad=1)
+        assert np.array_equal(cpu(out0), r0) and np.array_equal(cpu(out2), r2)
+        assert np.array_equal(cpu(blend), r_blend)
+        only = torch.full_like(blend, float("nan"))
+        assert cabi.filterinterp_blend_forward(*args, only, None, None, w0, w2) == 0
+        assert torch.equal(only, blend)
+    assert cabi.filterinterp_blend_forward(args[0], args[1][:, :, :, :-1] if W > 1 else args[1][:, :0], *args[2:], blend,
+                                           out0, out2, 0.5, 0.5) == 1
+
+
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("shape", [(1, 3, 9, 13), (2, 4, 16, 22), (1, 1, 1, 1), (1, 196, 18, 31)])
+def test_pwc_warp_bit_exact(torch_mod, cabi, oracle, shape, align_corners):
+    torch = torch_mod
+    rng = np.random.default_rng(sum(shape) + int(align_corners))
+    B, C, H, W = shape
+    feat = rng.normal(size=shape).astype(f32)
+    for scale in (0.7, 3.0, 40.0, 1e12):
+        flo = (rng.normal(size=(B, 2, H, W)) * scale).astype(f32)
+        out = torch.full(shape, float("nan"), device="cuda:0")
+        assert cabi.pwc_warp_forward(gpu(torch, feat), gpu(torch, flo), out, align_corners) == 0
+        assert np.array_equal(cpu(out), oracle.pwc_warp(feat, flo, align_corners, fmad=1))
+    assert cabi.pwc_warp_forward(gpu(torch, feat), gpu(torch, np.zeros((B, 3, H, W), f32)), out, True) == 1
+
+
+def test_frame_boundary(torch_mod, cabi, oracle):
+    torch = torch_mod
+    from vfidkr_amd import fused
+    rng = np.random.default_rng(11)
+    for (b, h, w) in ((2, 9, 14), (1, 37, 130), (1, 1, 1)):
+        u8 = rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+        for pad in ((3, 2, 4, 1), (0, 0, 0, 0), (32, 32, 16, 16)):
+            left, right, top, bottom = pad
+            dst = torch.full((b, 3, h + top + bottom, w + left + right), float("nan"), device="cuda:0")
+            assert cabi.frame_u8_to_planar(torch.from_numpy(u8).cuda(), dst, *pad) == 0
+            ref = oracle.frame_to_padded(u8, *pad)
+            assert np.array_equal(cpu(dst), ref)
+            # back: values below 0, above 1 and exact ties included
+            y = (ref * f32(1.3) - f32(0.1)).astype(f32)
+            y[..., 0, 0] = f32(0.5) / f32(255.0)
+            back = torch.zeros((b, h, w, 3), dtype=torch.uint8, device="cuda:0")
+            assert cabi.planar_to_frame_u8(gpu(torch, y), back, top, left) == 0
+            assert np.array_equal(back.cpu().numpy(), oracle.padded_to_frame(y, h, w, left, top))
+    ties = np.array([-0.2, 0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.999, 1.0, 7.0], f32).reshape(1, 1, 1, 8).repeat(3, 1)
+    back = torch.zeros((1, 1, 8, 3), dtype=torch.uint8, device="cuda:0")
+    assert cabi.planar_to_frame_u8(gpu(torch, ties), back, 0, 0) == 0
+    assert back.cpu().numpy()[0, 0, :, 0].tolist() == [0, 0, 0, 2, 2, 255, 255, 255]
+    # error sums are exact integers; PSNR / interpolation error as demo_MiddleBury.py computes them
+    a = rng.integers(0, 256, (2, 33, 65, 3), dtype=np.uint8)
+    bb = rng.integers(0, 256, (2, 33, 65, 3), dtype=np.uint8)
+    sums = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    assert cabi.frame_error_sums(torch.from_numpy(a).cuda(), torch.from_numpy(bb).cuda(), sums) == 0
+    d = a.astype(np.int64) - bb.astype(np.int64)
+    assert sums.cpu().tolist() == [int(np.abs(d).sum()), int((d * d).sum())]
+    err, psnr = fused.interpolation_error_and_psnr(torch.from_numpy(a).cuda(), torch.from_numpy(bb).cuda())
+    r_err, r_psnr = oracle.frame_error(a, bb)
+    assert abs(err - r_err) <= 1e-12 and abs(psnr - r_psnr) <= 1e-9
+    # the whole boundary through the host mirror: pad, crop back, identical frame, infinite PSNR
+    frames = torch.from_numpy(rng.integers(0, 256, (1, 40, 72, 3), dtype=np.uint8)).cuda()
+    x, padding = fused.frames_to_padded(frames)
+    assert tuple(x.shape) == (1, 3, 128, 128) and padding == (28, 28, 44, 44)
+    assert torch.equal(fused.padded_to_frames(x, 40, 72, padding), frames)
+    assert fused.interpolation_error_and_psnr(fused.padded_to_frames(x, 40, 72, padding), frames) == (0.0, float("inf"))
+
+
+def test_fused_host_mirror(torch_mod, cabi, oracle):
+    """`fused.py`: the reference helpers' names on the fused entry points."""
+    torch = torch_mod
+    from vfidkr_amd import fused
+    rng = np.random.default_rng(5)
+    flow_q = (rng.normal(size=(1, 2, 8, 12)) * 0.2).astype(f32)
+    ups = fused.forward_flownets_upsample(gpu(torch, flow_q), 20.0, [0.25, 0.5])
+    assert np.array_equal(cpu(ups[1]), oracle.flow_upsample4(flow_q, 20.0, 0.5, fmad=1))
+    depth = rng.uniform(0.1, 1.0, (1, 1, 32, 48)).astype(f32)
+    proj = fused.FlowProject_from_quarter(gpu(torch, flow_q), 20.0, [0.25, 0.5], gpu(torch, depth))
+    r_out, _ = oracle.flowproj_up4_fwd(flow_q, 20.0, 0.5, 1, depth, fmad=1)
+    assert close(cpu(proj[1]), r_out, 1e-4)
+    ref0, ref2 = rng.random((1, 3, 32, 48), dtype=f32), rng.random((1, 3, 32, 48), dtype=f32)
+    filt = rng.random((1, 16, 32, 48), dtype=f32)
+    off = [proj[0], proj[1]]
+    blend, o0, o2 = fused.FilterInterpolate(gpu(torch, ref0), gpu(torch, ref2), off, [gpu(torch, filt)] * 2, 16, 0.25)
+    rb, r0, r2 = oracle.filterinterp_blend(ref0, ref2, cpu(off[0]), cpu(off[1]), filt, filt, 0.75, 0.25, fmad=1)
+    assert np.array_equal(cpu(blend), rb) and np.array_equal(cpu(o0), r0) and np.array_equal(cpu(o2), r2)
+    feat = rng.normal(size=(1, 8, 32, 48)).astype(f32)
+    assert np.array_equal(cpu(fused.warp(gpu(torch, feat), off[0])), oracle.pwc_warp(feat, cpu(off[0]), True, fmad=1))
+
+
 # ------------------------------------------------------------------ golden fixtures (no oracle involved)
 
 def test_against_golden_fixtures(torch_mod, cabi, golden_dir):
@@ -444,6 +598,28 @@ def test_against_golden_fixtures(torch_mod, cabi, golden_dir):
     out5 = torch.zeros_like(img[:1])
     assert cabi.filterinterp_forward_ori(img[:1].contiguous(), flow[:1].contiguous(), gpu(torch, g["fi5_filt"]), out5) == 0
     assert close(cpu(out5), g["fi5_out"])
+    gl = np.load(os.path.join(golden_dir, "glue.npz"))
+    up = torch.empty((2, 2, 24, 36), device="cuda:0")
+    assert cabi.flow_upsample4(gpu(torch, gl["flow_q"]), up, 20.0, 0.25) == 0
+    assert close(cpu(up), gl["up4"])
+    for fh in (0, 1):
+        cnt, po = torch.empty((2, 1, 24, 36), device="cuda:0"), torch.empty((2, 2, 24, 36), device="cuda:0")
+        assert cabi.flowprojection_forward_up4(gpu(torch, gl["flow_q"]), cnt, po, 20.0, 0.25, fh) == 0
+        assert np.array_equal(cpu(cnt), gl["proj_up4_count_fh%d" % fh]) and close(cpu(po), gl["proj_up4_fh%d" % fh], 1e-4)
+    for ac in (0, 1):
+        wo = torch.empty((2, 4, 12, 17), device="cuda:0")
+        assert cabi.pwc_warp_forward(gpu(torch, gl["feat"]), gpu(torch, gl["flo"]), wo, bool(ac)) == 0
+        assert close(cpu(wo), gl["warp_ac%d" % ac])
+    bl = torch.empty((1, 3, 32, 48), device="cuda:0")
+    assert cabi.filterinterp_blend_forward(*(gpu(torch, gl[k]) for k in ("ref0", "ref2", "flow0", "flow2", "filt0", "filt2")),
+                                           bl, None, None, 0.75, 0.25) == 0
+    assert close(cpu(bl), gl["blend"])
+    fp = torch.empty((2, 3, 14, 19), device="cuda:0")
+    assert cabi.frame_u8_to_planar(torch.from_numpy(gl["frame_u8"]).cuda(), fp, 3, 2, 4, 1) == 0
+    assert np.array_equal(cpu(fp), gl["frame_padded"])
+    fb = torch.zeros((2, 9, 14, 3), dtype=torch.uint8, device="cuda:0")
+    assert cabi.planar_to_frame_u8(gpu(torch, gl["frame_y"]), fb, 4, 3) == 0
+    assert np.array_equal(fb.cpu().numpy(), gl["frame_back"])
     g1, g2, g3 = torch.zeros_like(img), torch.zeros_like(flow), torch.zeros_like(filt)
     assert cabi.filterinterp_backward_ori(img, flow, filt, gpu(torch, g["fi_gout"]), g1, g2, g3) == 0
     assert close(cpu(g1), g["fi_gimg"], 1e-4) and close(cpu(g2), g["fi_gflow"], 1e-4) and close(cpu(g3), g["fi_gfilt"], 1e-4)

@@ -380,6 +380,94 @@ def test_correlation_backward_adjoint(oracle):
         assert abs(_dot(g, oracle.correlation_fwd(f1, d, pad, k, md, 1, s2)) - _dot(g2, d)) <= 1e-3
 
 
+# ------------------------------------------------------------------ 3b. glue either side of the ops
+# The reference does these steps with torch built-ins; the oracle restates ATen's kernels and is
+# pinned here against the torch CPU build of this image (the dependency itself, importable).
+
+def _torch_warp(feat, flo, align_corners):
+    """PWCDCNet.warp written out with torch CPU ops (PWCNet/PWCNet.py:159-199)."""
+    import torch
+    x, flo = torch.from_numpy(feat), torch.from_numpy(flo)
+    B, C, H, W = x.shape
+    xx = torch.arange(0, W).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1)
+    yy = torch.arange(0, H).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1)
+    vgrid = torch.cat((xx, yy), 1).float() + flo
+    vgrid[:, 0, :, :] = 2.0 * vgrid[:, 0, :, :].clone() / max(W - 1, 1) - 1.0
+    vgrid[:, 1, :, :] = 2.0 * vgrid[:, 1, :, :].clone() / max(H - 1, 1) - 1.0
+    vgrid = vgrid.permute(0, 2, 3, 1)
+    output = torch.nn.functional.grid_sample(x, vgrid, align_corners=align_corners)
+    mask = torch.nn.functional.grid_sample(torch.ones(x.size()), vgrid, align_corners=align_corners)
+    mask[mask < 0.9999] = 0
+    mask[mask > 0] = 1
+    return (output * mask).numpy()
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 8, 11), (2, 2, 5, 7), (1, 3, 1, 1), (1, 2, 1, 9), (1, 2, 18, 31)])
+def test_flow_upsample4_matches_torch(oracle, shape):
+    import torch
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(size=shape).astype(f32)
+    for m0, m1 in ((20.0, 0.5), (20.0, 0.25), (1.0, 1.0)):
+        ref = torch.nn.Upsample(scale_factor=4, mode="bilinear")(torch.from_numpy((m0 * x) * f32(m1))).numpy()
+        for fmad in (0, 1):
+            got = oracle.flow_upsample4(x, m0, m1, fmad)
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    # a constant stays that constant exactly (1.5 and the weights are dyadic); the first corner is the
+    # first input value (source index clamped to 0), the last one is it to rounding (l0*p + l1*p)
+    c = oracle.flow_upsample4(np.full(shape, 1.5, f32), 2.0, 0.5)
+    assert np.array_equal(c, np.full(c.shape, 1.5, f32))
+    got = oracle.flow_upsample4(x, 1.0, 1.0)
+    assert np.array_equal(got[:, :, 0, 0], x[:, :, 0, 0])
+    assert np.abs(got[:, :, -1, -1] - x[:, :, -1, -1]).max() <= 2.4e-7 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("shape", [(1, 3, 9, 13), (2, 4, 16, 22), (1, 1, 1, 1), (1, 2, 2, 40)])
+def test_pwc_warp_matches_torch(oracle, shape, align_corners):
+    rng = np.random.default_rng(sum(shape) + int(align_corners))
+    B, C, H, W = shape
+    feat = rng.normal(size=shape).astype(f32)
+    for scale in (0.7, 3.0, 40.0):
+        flo = (rng.normal(size=(B, 2, H, W)) * scale).astype(f32)
+        ref = _torch_warp(feat, flo, align_corners)
+        for fmad in (0, 1):
+            got = oracle.pwc_warp(feat, flo, align_corners, fmad)
+            # a sample whose ones-mask sits within rounding of the 0.9999 threshold may flip: none here
+            assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(feat).max()), (scale, fmad)
+    # everything far outside: zeros (align_corners=True collapses a size-1 axis onto its only pixel)
+    if not align_corners or (H > 1 and W > 1):
+        assert not oracle.pwc_warp(feat, np.full((B, 2, H, W), 1e4, f32), align_corners).any()
+    if align_corners and H > 1 and W > 1:
+        # zero flow: the normalisation round-trips to the pixel itself (to rounding)
+        got = oracle.pwc_warp(feat, np.zeros((B, 2, H, W), f32), True)
+        assert np.abs(got - feat).max() <= 1e-5
+
+
+def test_frame_boundary_restatement(oracle):
+    from vfidkr_amd import fused                      # host logic only: no GPU needed for padding_for
+    assert fused.padding_for(480, 640) == (32, 32, 16, 16)          # -> 512 x 704 (demo_MiddleBury.py:317)
+    assert fused.padding_for(1080, 1920) == (32, 32, 36, 36)        # -> 1152 x 1984
+    assert fused.padding_for(256, 448) == (32, 32, 32, 32)          # -> 320 x 512
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (2, 9, 14, 3), dtype=np.uint8)
+    left, right, top, bottom = 3, 2, 4, 1
+    x = oracle.frame_to_padded(u8, left, right, top, bottom)
+    assert x.dtype == f32 and x.shape == (2, 3, 9 + 5, 14 + 5)
+    assert np.array_equal(x[:, :, 0, 0], u8[:, 0, 0, :].astype(f32) / f32(255.0))            # replicated corner
+    assert np.array_equal(oracle.padded_to_frame(x, 9, 14, left, top), u8)                    # exact round trip
+    # rounding is half to even on 255 * y, clipping first
+    y = np.array([-0.2, 0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.999, 1.0, 7.0], f32).reshape(1, 1, 1, 8).repeat(3, 1)
+    assert oracle.padded_to_frame(y, 1, 8, 0, 0)[0, 0, :, 0].tolist() == [0, 0, 0, 2, 2, 255, 255, 255]
+    a = rng.integers(0, 256, (1, 5, 6, 3), dtype=np.uint8)
+    err, psnr = oracle.frame_error(a, a)
+    assert err == 0.0 and psnr == float("inf")
+    b = a.copy()
+    b[0, 0, 0, 0] = a[0, 0, 0, 0] ^ 0x10
+    err, psnr = oracle.frame_error(a, b)
+    assert abs(err - 16.0 / a.size) < 1e-12 and abs(psnr - 20 * np.log10(255.0 / np.sqrt(256.0 / a.size))) < 1e-9
+
+
 # ------------------------------------------------------------------ 4. golden fixtures still hold
 
 def test_golden_fixtures_reproduced(oracle, golden_dir):
@@ -396,6 +484,19 @@ def test_golden_fixtures_reproduced(oracle, golden_dir):
     # the two copy-through pixels planted by the generator
     assert np.array_equal(g["fi_out"][0, :, 5, 7], img[0, :, 5, 7])
     assert np.array_equal(g["fi_out"][1, :, 0, 0], img[1, :, 0, 0])
+
+    g = np.load(os.path.join(golden_dir, "glue.npz"))
+    assert np.array_equal(oracle.flow_upsample4(g["flow_q"], 20.0, 0.25), g["up4"])
+    for fh in (0, 1):
+        out, count = oracle.flowproj_up4_fwd(g["flow_q"], 20.0, 0.25, fh, fmad=0)
+        assert np.array_equal(out, g["proj_up4_fh%d" % fh]) and np.array_equal(count, g["proj_up4_count_fh%d" % fh])
+    for ac in (0, 1):
+        assert np.array_equal(oracle.pwc_warp(g["feat"], g["flo"], bool(ac)), g["warp_ac%d" % ac])
+    blend, o0, o2 = oracle.filterinterp_blend(g["ref0"], g["ref2"], g["flow0"], g["flow2"], g["filt0"], g["filt2"],
+                                              0.75, 0.25)
+    assert np.array_equal(blend, g["blend"]) and np.array_equal(o0, g["blend_out0"]) and np.array_equal(o2, g["blend_out2"])
+    assert np.array_equal(oracle.frame_to_padded(g["frame_u8"], 3, 2, 4, 1), g["frame_padded"])
+    assert np.array_equal(oracle.padded_to_frame(g["frame_y"], 9, 14, 3, 4), g["frame_back"])
 
     g = np.load(os.path.join(golden_dir, "projection.npz"))
     for fh in (0, 1):

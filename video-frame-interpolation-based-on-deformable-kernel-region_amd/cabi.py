@@ -14,6 +14,7 @@ import torch  # must be imported before libvfi_hip.so so both bind the same liba
 from . import LIB_PATH
 
 _i = ctypes.c_int
+_f = ctypes.c_float
 _p = ctypes.c_void_p
 
 
@@ -47,6 +48,17 @@ SIGNATURES = {
                                     ctypes.POINTER(_i)],
     "vfi_correlation_forward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "vfi_correlation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    # glue either side of the ops
+    "vfi_flow_upsample4": [_p, _p, _i, _i, _i, _i, _f, _f, Strides, Strides, _p],
+    "vfi_flowprojection_forward_up4": [_p, _p, _p, _i, _i, _i, _f, _f, _i, Strides, Strides, Strides, _p],
+    "vfi_depthflowprojection_forward_up4": [_p, _p, _p, _p, _i, _i, _i, _f, _f, _i, Strides, Strides, Strides, Strides,
+                                            _p],
+    "vfi_filterinterp_blend_forward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, Strides, Strides,
+                                       Strides, Strides, _p],
+    "vfi_pwc_warp_forward": [_p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_frame_u8_to_planar": [_p, _p, _i, _i, _i, _i, _i, _i, _i, Strides, _p],
+    "vfi_planar_to_frame_u8": [_p, _p, _i, _i, _i, _i, _i, Strides, _p],
+    "vfi_frame_error_sums": [_p, _p, ctypes.c_int64, _p, _p],
 }
 # internal entry points used by the bench / tests to time one code path in isolation
 INTERNAL_SIGNATURES = {
@@ -84,11 +96,11 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _dev(t):
+def _dev(t, dtype=torch.float32):
     if not t.is_cuda:
         raise RuntimeError("vfidkr_amd.cabi: tensors must live on the GPU (there is no CPU path)")
-    if t.dtype != torch.float32:
-        raise RuntimeError("vfidkr_amd.cabi: tensors must be float32")
+    if t.dtype != dtype:
+        raise RuntimeError("vfidkr_amd.cabi: tensors must be %s" % str(dtype).replace("torch.", ""))
     return t.device
 
 
@@ -364,3 +376,115 @@ def correlation_backward(input1, input2, gradoutput, pad_size, kernel_size, max_
     if err != 0:
         raise RuntimeError("CUDA call failed")
     return g1, g2
+
+
+# ---------------------------------------------------------------- glue either side of the ops
+
+def _nchw_ok(*tensors):
+    return all(t.dim() == 4 and t.stride(3) == 1 for t in tensors)
+
+
+def flow_upsample4(input, output, mul0, mul1):
+    b, c, hq, wq = input.shape
+    if not _nchw_ok(input, output) or tuple(output.shape) != (b, c, 4 * hq, 4 * wq):
+        return 1
+    _dev(output)
+    with torch.cuda.device(_dev(input)):
+        return _finish(lib().vfi_flow_upsample4(_ptr(input), _ptr(output), b, c, hq, wq, mul0, mul1, _st(input),
+                                                _st(output), _stream(input)))
+
+
+def flowprojection_forward_up4(flow_q, count, output, mul0, mul1, fillhole):
+    b, c, hq, wq = flow_q.shape
+    if c != 2 or not _nchw_ok(flow_q, count, output):
+        return 1
+    if tuple(output.shape) != (b, 2, 4 * hq, 4 * wq) or tuple(count.shape) != (b, 1, 4 * hq, 4 * wq):
+        return 1
+    _dev(count), _dev(output)
+    with torch.cuda.device(_dev(flow_q)):
+        return _finish(lib().vfi_flowprojection_forward_up4(_ptr(flow_q), _ptr(count), _ptr(output), b, hq, wq, mul0,
+                                                            mul1, int(fillhole), _st(flow_q), _st(count), _st(output),
+                                                            _stream(flow_q)))
+
+
+def depthflowprojection_forward_up4(flow_q, input2, count, output, mul0, mul1, fillhole):
+    b, c, hq, wq = flow_q.shape
+    if c != 2 or not _nchw_ok(flow_q, input2, count, output):
+        return 1
+    full = (b, 1, 4 * hq, 4 * wq)
+    if tuple(output.shape) != (b, 2, 4 * hq, 4 * wq) or tuple(count.shape) != full or tuple(input2.shape) != full:
+        return 1
+    _dev(input2), _dev(count), _dev(output)
+    with torch.cuda.device(_dev(flow_q)):
+        return _finish(lib().vfi_depthflowprojection_forward_up4(
+            _ptr(flow_q), _ptr(input2), _ptr(count), _ptr(output), b, hq, wq, mul0, mul1, int(fillhole), _st(flow_q),
+            _st(input2), _st(count), _st(output), _stream(flow_q)))
+
+
+def _same_strides(a, b):
+    return a.shape == b.shape and a.stride() == b.stride()
+
+
+def filterinterp_blend_forward(ref0, ref2, flow0, flow2, filt0, filt2, blend, out0, out2, w0, w2):
+    """out0 / out2 may be None."""
+    dims = _fi_checks(ref0, flow0, filt0, None)
+    if dims is None or not (_same_strides(ref0, ref2) and _same_strides(flow0, flow2) and _same_strides(filt0, filt2)):
+        return 1
+    outs = [t for t in (out0, out2) if t is not None]
+    if blend.shape != ref0.shape or blend.stride(3) != 1 or not all(_same_strides(blend, t) for t in outs):
+        return 1
+    b, c, h, w = dims
+    for t in (ref2, flow0, flow2, filt0, filt2, blend, *outs):
+        _dev(t)
+    null = ctypes.c_void_p(0)
+    with torch.cuda.device(_dev(ref0)):
+        return _finish(lib().vfi_filterinterp_blend_forward(
+            _ptr(ref0), _ptr(ref2), _ptr(flow0), _ptr(flow2), _ptr(filt0), _ptr(filt2), _ptr(blend),
+            _ptr(out0) if out0 is not None else null, _ptr(out2) if out2 is not None else null, b, c, h, w,
+            filt0.size(1), w0, w2, _st(ref0), _st(flow0), _st(filt0), _st(blend), _stream(ref0)))
+
+
+def pwc_warp_forward(x, flow, output, align_corners=True):
+    b, c, h, w = x.shape
+    if not _nchw_ok(x, flow, output) or tuple(flow.shape) != (b, 2, h, w) or output.shape != x.shape:
+        return 1
+    _dev(flow), _dev(output)
+    with torch.cuda.device(_dev(x)):
+        return _finish(lib().vfi_pwc_warp_forward(_ptr(x), _ptr(flow), _ptr(output), b, c, h, w, int(bool(align_corners)),
+                                                  _st(x), _st(flow), _st(output), _stream(x)))
+
+
+def frame_u8_to_planar(src_hwc, dst, pad_left, pad_right, pad_top, pad_bottom):
+    """src_hwc: dense uint8 [B,h,w,3]; dst: float32 [B,3,h+pt+pb,w+pl+pr]."""
+    b, h, w, c = src_hwc.shape
+    if c != 3 or not src_hwc.is_contiguous() or dst.stride(3) != 1:
+        return 1
+    if tuple(dst.shape) != (b, 3, h + pad_top + pad_bottom, w + pad_left + pad_right):
+        return 1
+    _dev(dst)
+    with torch.cuda.device(_dev(src_hwc, torch.uint8)):
+        return _finish(lib().vfi_frame_u8_to_planar(_ptr(src_hwc), _ptr(dst), b, h, w, pad_left, pad_right, pad_top,
+                                                    pad_bottom, _st(dst), _stream(dst)))
+
+
+def planar_to_frame_u8(src, dst_hwc, top, left):
+    """src: float32 [B,3,H,W]; dst_hwc: dense uint8 [B,h,w,3], the crop at (top, left)."""
+    b, h, w, c = dst_hwc.shape
+    if c != 3 or not dst_hwc.is_contiguous() or src.stride(3) != 1 or src.size(0) != b or src.size(1) != 3:
+        return 1
+    if top < 0 or left < 0 or top + h > src.size(2) or left + w > src.size(3):
+        return 1
+    _dev(dst_hwc, torch.uint8)
+    with torch.cuda.device(_dev(src)):
+        return _finish(lib().vfi_planar_to_frame_u8(_ptr(src), _ptr(dst_hwc), b, h, w, top, left, _st(src),
+                                                    _stream(src)))
+
+
+def frame_error_sums(a, b, sums):
+    """a, b: dense uint8 tensors of one shape; sums: int64[2] on the GPU, zeroed by the caller."""
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous() or sums.numel() < 2:
+        return 1
+    _dev(b, torch.uint8), _dev(sums, torch.int64)
+    with torch.cuda.device(_dev(a, torch.uint8)):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        return _finish(lib().vfi_frame_error_sums(_ptr(a), _ptr(b), a.numel(), _ptr(sums), stream))

@@ -16,35 +16,6 @@ namespace vfi {
 
 // ------------------------------------------------------------------ forward, _ori
 
-// quadrant sums for a runtime filter size, rows outer / columns inner per quadrant
-__device__ __forceinline__ void quadrants_generic(const float* __restrict__ plane, const float* __restrict__ fpx,
-                                                  int64_t fcs, int hs, int h, int w, int fs,
-                                                  int L, int T, int ix, int iy, float q[4]) {
-    const int R = L + fs, Bm = T + fs;
-    float TL = 0.0f, TR = 0.0f, BL = 0.0f, BR = 0.0f;
-    for (int j = T; j <= iy; ++j) {
-        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
-        for (int i = L; i <= ix; ++i)
-            TL = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], TL);
-    }
-    for (int j = T; j <= iy; ++j) {
-        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
-        for (int i = ix + 1; i < R; ++i)
-            TR = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], TR);
-    }
-    for (int j = iy + 1; j < Bm; ++j) {
-        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
-        for (int i = L; i <= ix; ++i)
-            BL = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], BL);
-    }
-    for (int j = iy + 1; j < Bm; ++j) {
-        const float* row = plane + (int64_t)clampi(j, 0, h - 1) * hs;
-        for (int i = ix + 1; i < R; ++i)
-            BR = fmaf(row[clampi(i, 0, w - 1)], fpx[(int64_t)((j - T) * fs + (i - L)) * fcs], BR);
-    }
-    q[0] = TL; q[1] = TR; q[2] = BL; q[3] = BR;
-}
-
 template <bool FS4>
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,

@@ -1,0 +1,222 @@
+// glue.hip -- the steps immediately either side of the hot-path ops, as single
+// launches for gfx950:
+//   * FilterInterpolate of both reference frames + the time-weighted blend
+//     (networks/DAIN_slowmotion.py:324-335, networks/DAIN.py:560-573);
+//   * PWC-Net's warp(): grid normalisation, grid_sample of the features and of a ones mask,
+//     threshold, multiply (PWCNet/PWCNet.py:159-199);
+//   * the frame boundary: uint8 HWC -> float32 CHW / 255 with replication padding, and back
+//     (clip, crop, x255, round half to even, uint8), plus the sums behind PSNR and the
+//     interpolation error (demo_MiddleBury.py:280-318, 350-364, 370-388).
+// (The x4 flow upsample fused into the projection is in projection.hip.)
+#include "filterinterp_dev.h"
+
+namespace vfi {
+
+// ------------------------------------------------------------------ FilterInterpolate x2 + blend
+
+struct FiSide {
+    bool valid;
+    int L, T, ix, iy;
+    float alpha, beta;
+};
+__device__ __forceinline__ FiSide fi_side(const float* __restrict__ flow, int64_t cstride, int x, int y, int w, int h, int fs) {
+    FiSide s;
+    const float fx = flow[0], fy = flow[cstride];
+    const float x2 = (float)x + fx, y2 = (float)y + fy;
+    s.valid = fi_valid(fx, fy, x2, y2, w, h);
+    s.ix = s.valid ? (int)x2 : 0;
+    s.iy = s.valid ? (int)y2 : 0;
+    s.L = s.ix + 1 - fs / 2;
+    s.T = s.iy + 1 - fs / 2;
+    s.alpha = x2 - (float)s.ix;
+    s.beta = y2 - (float)s.iy;
+    return s;
+}
+__device__ __forceinline__ float fi_side_value(const FiSide& s, const float* __restrict__ plane, const float* __restrict__ fpx,
+                                               int64_t fcs, int hs, int h, int w, int fs, int x, int y) {
+    if (!s.valid) return plane[(int64_t)y * hs + x];       // copy-through (:2814-2818)
+    float q[4];
+    quadrants_generic(plane, fpx, fcs, hs, h, w, fs, s.L, s.T, s.ix, s.iy, q);
+    return blend4(s.alpha, s.beta, q[0], q[1], q[2], q[3]);
+}
+
+// out0 = FI(ref0, flow0, filt0), out2 = FI(ref2, flow2, filt2), blend = out0 * w0 + out2 * w2 with the
+// two products rounded separately (torch evaluates a*(1-t) + b*t as three elementwise ops)
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_blend_forward(
+    const float* __restrict__ ref0, const float* __restrict__ ref2, const float* __restrict__ flow0,
+    const float* __restrict__ flow2, const float* __restrict__ filt0, const float* __restrict__ filt2,
+    float* __restrict__ blend, float* __restrict__ out0, float* __restrict__ out2,
+    int channel, int h, int w, int fs, float w0, float w2,
+    vfi_strides sr, vfi_strides sf, vfi_strides sk, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const int64_t fo = (int64_t)b * sf.b + (int64_t)y * sf.h + x, ko = (int64_t)b * sk.b + (int64_t)y * sk.h + x;
+    const FiSide a = fi_side(flow0 + fo, sf.c, x, y, w, h, fs), c2 = fi_side(flow2 + fo, sf.c, x, y, w, h, fs);
+    const int64_t oo = (int64_t)b * so.b + (int64_t)y * so.h + x;
+    for (int c = 0; c < channel; ++c) {
+        const float v0 = fi_side_value(a, ref0 + (int64_t)b * sr.b + (int64_t)c * sr.c, filt0 + ko, sk.c, (int)sr.h, h, w, fs, x, y);
+        const float v2 = fi_side_value(c2, ref2 + (int64_t)b * sr.b + (int64_t)c * sr.c, filt2 + ko, sk.c, (int)sr.h, h, w, fs, x, y);
+        if (out0) out0[oo + (int64_t)c * so.c] = v0;
+        if (out2) out2[oo + (int64_t)c * so.c] = v2;
+        const float p0 = v0 * w0, p2 = v2 * w2;
+        blend[oo + (int64_t)c * so.c] = p0 + p2;
+    }
+}
+
+// ------------------------------------------------------------------ PWC-Net warp()
+
+// vgrid = pixel + flow; normalised as PWCNet.py:184-185; grid_sample (bilinear, zeros padding) of x
+// and of a ones tensor; mask = (ones sample >= 0.9999); out = sample * mask.  align_corners selects
+// grid_sample's un-normalisation: 1 = torch <= 1.2 (what the reference was written for: the
+// normalisation above then round-trips to pixel + flow), 0 = the default of torch >= 1.3.
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void pwc_warp_forward(
+    const float* __restrict__ xin, const float* __restrict__ flo, float* __restrict__ out,
+    int channel, int h, int w, int align_corners, vfi_strides sx, vfi_strides sf, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* f = flo + (int64_t)b * sf.b + (int64_t)y * sf.h + x;
+    const float vx = (float)x + f[0], vy = (float)y + f[sf.c];
+    const float gx = 2.0f * vx / (float)max(w - 1, 1) - 1.0f;
+    const float gy = 2.0f * vy / (float)max(h - 1, 1) - 1.0f;
+    // ATen grid_sampler_unnormalize
+    const float ix = align_corners ? ((gx + 1.0f) / 2.0f) * (float)(w - 1) : ((gx + 1.0f) * (float)w - 1.0f) / 2.0f;
+    const float iy = align_corners ? ((gy + 1.0f) / 2.0f) * (float)(h - 1) : ((gy + 1.0f) * (float)h - 1.0f) / 2.0f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    // corners as ATen orders them: nw, ne, sw, se; weights from the opposite corner
+    const float wnw = (fx0 + 1.0f - ix) * (fy0 + 1.0f - iy), wne = (ix - fx0) * (fy0 + 1.0f - iy);
+    const float wsw = (fx0 + 1.0f - ix) * (iy - fy0), wse = (ix - fx0) * (iy - fy0);
+    // float -> int of a huge or NaN coordinate is undefined in C; such a corner is out of bounds anyway
+    const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
+    const bool inx0 = x0 >= 0 && x0 < w, inx1 = x0 + 1 >= 0 && x0 + 1 < w;
+    const bool iny0 = y0 >= 0 && y0 < h, iny1 = y0 + 1 >= 0 && y0 + 1 < h;
+    float m = 0.0f;
+    if (iny0 && inx0) m += wnw;
+    if (iny0 && inx1) m += wne;
+    if (iny1 && inx0) m += wsw;
+    if (iny1 && inx1) m += wse;
+    const float mask = (m < 0.9999f) ? 0.0f : (m > 0.0f ? 1.0f : m);   // mask[mask<0.9999]=0; mask[mask>0]=1 (NaN stays)
+    const float* src = xin + (int64_t)b * sx.b;
+    float* dst = out + (int64_t)b * so.b + (int64_t)y * so.h + x;
+    for (int c = 0; c < channel; ++c) {
+        const float* p = src + (int64_t)c * sx.c;
+        float v = 0.0f;
+        // out_acc += value * weight, fused as nvcc fuses ATen's grid_sampler
+        if (iny0 && inx0) v = fmaf(p[(int64_t)y0 * sx.h + x0], wnw, v);
+        if (iny0 && inx1) v = fmaf(p[(int64_t)y0 * sx.h + x0 + 1], wne, v);
+        if (iny1 && inx0) v = fmaf(p[(int64_t)(y0 + 1) * sx.h + x0], wsw, v);
+        if (iny1 && inx1) v = fmaf(p[(int64_t)(y0 + 1) * sx.h + x0 + 1], wse, v);
+        dst[(int64_t)c * so.c] = v * mask;
+    }
+}
+
+// ------------------------------------------------------------------ frame boundary
+
+// dst[c][y][x] = src[clamp(y - top)][clamp(x - left)][c] / 255  (astype(float32) / 255.0, ReplicationPad2d)
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void frame_u8_to_planar(
+    const unsigned char* __restrict__ src, float* __restrict__ dst, int h, int w, int top, int left, int ph, int pw,
+    vfi_strides sd) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= pw || y >= ph) return;
+    const int b = blockIdx.z;
+    const unsigned char* p = src + ((int64_t)b * h * w + (int64_t)clampi(y - top, 0, h - 1) * w + clampi(x - left, 0, w - 1)) * 3;
+    float* d = dst + (int64_t)b * sd.b + (int64_t)y * sd.h + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[(int64_t)c * sd.c] = (float)p[c] / 255.0f;
+}
+
+// dst[y][x][c] = uint8(rint(255 * clip(src[c][top + y][left + x], 0, 1)))   (np.round: half to even)
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void planar_to_frame_u8(
+    const float* __restrict__ src, unsigned char* __restrict__ dst, int h, int w, int top, int left, vfi_strides ss) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* p = src + (int64_t)b * ss.b + (int64_t)(top + y) * ss.h + left + x;
+    unsigned char* d = dst + ((int64_t)b * h * w + (int64_t)y * w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = p[(int64_t)c * ss.c];
+        v = fminf(fmaxf(v, 0.0f), 1.0f);                    // NaN -> 0 here; numpy's clip keeps NaN (then astype is undefined)
+        d[c] = (unsigned char)(int)rintf(255.0f * v);
+    }
+}
+
+// sums[0] += sum |a - b|, sums[1] += sum (a - b)^2 over n bytes: exact integers
+__global__ __launch_bounds__(256) void frame_error_sums(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
+                                                        int64_t n, unsigned long long* __restrict__ sums) {
+    unsigned long long sa = 0ull, sq = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)a[i] - (int)b[i];
+        sa += (unsigned)(d < 0 ? -d : d);
+        sq += (unsigned)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sa += __shfl_xor(sa, o);
+        sq += __shfl_xor(sq, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], sa);
+        atomicAdd(&sums[1], sq);
+    }
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" int vfi_filterinterp_blend_forward(const float* ref0, const float* ref2, const float* flow0, const float* flow2,
+                                               const float* filt0, const float* filt2, float* blend, float* out0,
+                                               float* out2, int batch, int channel, int h, int w, int filter_channels,
+                                               float w0, float w2, vfi_strides s_ref, vfi_strides s_flow,
+                                               vfi_strides s_filt, vfi_strides s_out, vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!ref0 || !ref2 || !flow0 || !flow2 || !filt0 || !filt2 || !blend) return VFI_ERR_SHAPE;
+    const int fs = (int)sqrtf((float)filter_channels);
+    hipLaunchKernelGGL(fi_blend_forward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, ref0,
+                       ref2, flow0, flow2, filt0, filt2, blend, out0, out2, channel, h, w, fs, w0, w2, s_ref, s_flow,
+                       s_filt, s_out);
+    return launch_status();
+}
+
+extern "C" int vfi_pwc_warp_forward(const float* x, const float* flow, float* output, int batch, int channel, int h, int w,
+                                     int align_corners, vfi_strides sx, vfi_strides sf, vfi_strides so,
+                                     vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !x || !flow || !output) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(pwc_warp_forward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, x, flow,
+                       output, channel, h, w, align_corners ? 1 : 0, sx, sf, so);
+    return launch_status();
+}
+
+extern "C" int vfi_frame_u8_to_planar(const unsigned char* src_hwc, float* dst, int batch, int h, int w, int pad_left,
+                                       int pad_right, int pad_top, int pad_bottom, vfi_strides sd, vfi_stream_t stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || pad_left < 0 || pad_right < 0 || pad_top < 0 || pad_bottom < 0 || !src_hwc || !dst)
+        return VFI_ERR_SHAPE;
+    const int ph = h + pad_top + pad_bottom, pw = w + pad_left + pad_right;
+    hipLaunchKernelGGL(frame_u8_to_planar, pixel_grid(pw, ph, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       src_hwc, dst, h, w, pad_top, pad_left, ph, pw, sd);
+    return launch_status();
+}
+
+extern "C" int vfi_planar_to_frame_u8(const float* src, unsigned char* dst_hwc, int batch, int h, int w, int top, int left,
+                                       vfi_strides ss, vfi_stream_t stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || top < 0 || left < 0 || !src || !dst_hwc) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(planar_to_frame_u8, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, src,
+                       dst_hwc, h, w, top, left, ss);
+    return launch_status();
+}
+
+extern "C" int vfi_frame_error_sums(const unsigned char* a, const unsigned char* b, int64_t n, unsigned long long* sums,
+                                     vfi_stream_t stream) {
+    if (n <= 0 || !a || !b || !sums) return VFI_ERR_SHAPE;
+    const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(frame_error_sums, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, n, sums);
+    return launch_status();
+}

@@ -82,17 +82,59 @@ struct ProjSplat {
     float ax, ay, ac;
 };
 
-template <bool DEPTH>
-__device__ __forceinline__ ProjSplat proj_source(const float* __restrict__ in1, const float* __restrict__ in2,
-                                                 int b, int x, int y, int h, int w, vfi_strides s1, vfi_strides s2) {
+// Where the flow of a source pixel comes from.  UP == false: the full-resolution flow tensor of the
+// reference's FlowProjection.  UP == true: the network's quarter-resolution flow; the pixel's flow is
+// nn.Upsample(scale_factor=4, mode='bilinear') of (m0 * flow) * m1, formed on the fly -- the x4
+// upsampled tensor of forward_flownets (networks/DAIN_slowmotion.py:204-216) is never materialised.
+struct ProjFlow {
+    const float* p;
+    vfi_strides s;
+    int hq, wq;             // quarter-resolution size (UP only)
+    float m0, m1;           // div_flow, time offset (UP only)
+};
+
+// torch's upsample_bilinear2d, align_corners=False, scale factor 4 (ATen UpSampleBilinear2d):
+// source index 0.25 * (dst + 0.5) - 0.5 clamped at 0, second tap one further unless at the edge
+struct UpTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpTap up4_tap(int dst, int in_size) {
+    float src = 0.25f * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    UpTap t;
+    t.i0 = (int)src;
+    t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+// one channel at (x, y) of the upsampled (m0 * plane) * m1; fused as nvcc fuses ATen's expression
+__device__ __forceinline__ float up4_sample(const float* __restrict__ plane, int64_t hs, const UpTap& ty, const UpTap& tx,
+                                            float m0, float m1) {
+    const float p00 = (m0 * plane[(int64_t)ty.i0 * hs + tx.i0]) * m1, p01 = (m0 * plane[(int64_t)ty.i0 * hs + tx.i1]) * m1;
+    const float p10 = (m0 * plane[(int64_t)ty.i1 * hs + tx.i0]) * m1, p11 = (m0 * plane[(int64_t)ty.i1 * hs + tx.i1]) * m1;
+    const float t0 = fmaf(tx.l1, p01, tx.l0 * p00);
+    const float t1 = fmaf(tx.l1, p11, tx.l0 * p10);
+    return fmaf(ty.l1, t1, ty.l0 * t0);
+}
+
+template <bool DEPTH, bool UP>
+__device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float* __restrict__ in2,
+                                                 int b, int x, int y, int h, int w, vfi_strides s2) {
     ProjSplat s;
     s.valid = false;
     s.L = s.T = s.R = s.Bm = 0;
     s.ax = s.ay = s.ac = 0.0f;
     if (x >= w || y >= h) return s;
-    const float* flow = in1 + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-    const float fx = flow[0];
-    const float fy = flow[s1.c];
+    float fx, fy;
+    if constexpr (UP) {
+        const UpTap ty = up4_tap(y, f.hq), tx = up4_tap(x, f.wq);
+        const float* q = f.p + (int64_t)b * f.s.b;
+        fx = up4_sample(q, f.s.h, ty, tx, f.m0, f.m1);
+        fy = up4_sample(q + f.s.c, f.s.h, ty, tx, f.m0, f.m1);
+    } else {
+        const float* flow = f.p + (int64_t)b * f.s.b + (int64_t)y * f.s.h + x;
+        fx = flow[0];
+        fy = flow[f.s.c];
+    }
     const float x2 = (float)x + fx;
     const float y2 = (float)y + fy;
     if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1))) return s;
@@ -127,9 +169,9 @@ __device__ __forceinline__ int wmax(int v) {
 // segments that reach that tile and writes their ids (a returning atomic per segment and tile
 // measured 4x slower: the round trips serialise).
 #define PROJ_BIN_CAND 64            // candidate output tiles per source tile handled by the fast path
-template <bool DEPTH>
+template <bool DEPTH, bool UP>
 __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
-    const float* __restrict__ in1, const float* __restrict__ in2, ProjGeom g, vfi_strides s1, vfi_strides s2,
+    ProjFlow flow, const float* __restrict__ in2, ProjGeom g, vfi_strides s2,
     int* __restrict__ ws, int* __restrict__ bits, int serial) {
     __shared__ int rect[PROJ_TH][4];                        // per row segment: tx0, ty0, tx1, ty1 (tx0 < 0: none)
     __shared__ int tmax[2];
@@ -146,7 +188,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
     ProjSplat s[PROJ_TH / 4];
 #pragma unroll
     for (int r = 0; r < PROJ_TH / 4; ++r)                   // all loads first
-        s[r] = proj_source<DEPTH>(in1, in2, b, x, tyi * PROJ_TH + wave + r * 4, g.h, g.w, s1, s2);
+        s[r] = proj_source<DEPTH, UP>(flow, in2, b, x, tyi * PROJ_TH + wave + r * 4, g.h, g.w, s2);
     int vbits = 0, cbits = 0;
 #pragma unroll
     for (int r = 0; r < PROJ_TH / 4; ++r) {
@@ -201,9 +243,9 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
 }
 
 // B: one workgroup per output tile
-template <bool DEPTH>
+template <bool DEPTH, bool UP>
 __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
+    ProjFlow flow, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
     ProjGeom g, vfi_strides s1, vfi_strides s2, vfi_strides sc, int* __restrict__ ws, int* __restrict__ bits,
     int serial) {
     __shared__ unsigned long long acc[3][PROJ_TH][PROJ_TW];
@@ -239,8 +281,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
         float* cn = count + (int64_t)b * sc.b;
 #pragma unroll
         for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const ProjSplat s = proj_source<DEPTH>(in1, in2, b, txi * PROJ_TW + lane, tyi * PROJ_TH + wave + r * 4,
-                                                   g.h, g.w, s1, s2);
+            const ProjSplat s = proj_source<DEPTH, UP>(flow, in2, b, txi * PROJ_TW + lane, tyi * PROJ_TH + wave + r * 4,
+                                                       g.h, g.w, s2);
             if (!s.valid) continue;
             const int64_t oT = (int64_t)s.T * s1.h, oB = (int64_t)s.Bm * s1.h;
             const int64_t cT = (int64_t)s.T * sc.h, cB = (int64_t)s.Bm * sc.h;
@@ -261,8 +303,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     const int ids = (lane < mine) ? list[wave + lane * (PROJ_THREADS / 64)] : 0;
     auto fetch = [&](int j) {
         const int seg = __shfl(ids, j);
-        return proj_source<DEPTH>(in1, in2, b, (seg % g.tiles_x) * PROJ_TW + lane, seg / g.tiles_x - b * g.h,
-                                  g.h, g.w, s1, s2);
+        return proj_source<DEPTH, UP>(flow, in2, b, (seg % g.tiles_x) * PROJ_TW + lane, seg / g.tiles_x - b * g.h,
+                                      g.h, g.w, s2);
     };
     ProjSplat nxt = fetch(0);                               // lane 0 holds 0 when the wave has no entry: harmless
     for (int j = 0; j < mine; ++j) {
@@ -539,8 +581,9 @@ static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_wo
     return w;
 }
 
-template <bool DEPTH>
-static int project_forward(const float* in1, const float* in2, float* count, float* out, int batch, int h, int w,
+// s1 = strides of `out` (the reference binding shares them with the input flow)
+template <bool DEPTH, bool UP>
+static int project_forward(const ProjFlow& flow, const float* in2, float* count, float* out, int batch, int h, int w,
                            int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
     ProjGeom g;
     g.h = h; g.w = w;
@@ -558,13 +601,13 @@ static int project_forward(const float* in1, const float* in2, float* count, flo
     g.colmap = batch * h * g.rmw;
     ProjWorkspace* ws = proj_workspace(st, tile_words, bit_words);
     if (!ws) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL(proj_bin<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, g, s1, s2, ws->words,
+    hipLaunchKernelGGL((proj_bin<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, g, s2, ws->words,
                        ws->bits, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     hipLaunchKernelGGL(proj_zero, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL(proj_gather<DEPTH>, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, in1, in2, count, out, g, s1, s2,
-                       sc, ws->words, ws->bits, ws->serial);
+    hipLaunchKernelGGL((proj_gather<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, count, out, g, s1,
+                       s2, sc, ws->words, ws->bits, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
     hipLaunchKernelGGL(proj_average, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
@@ -576,6 +619,20 @@ static int project_forward(const float* in1, const float* in2, float* count, flo
     return VFI_OK;
 }
 
+// standalone x4 upsample of (m0 * in) * m1 -- forward_flownets as one launch
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void flow_upsample4(
+    const float* __restrict__ in, float* __restrict__ out, int channels, int hq, int wq, float m0, float m1,
+    vfi_strides sq, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= 4 * wq || y >= 4 * hq) return;
+    const int b = blockIdx.z;
+    const UpTap ty = up4_tap(y, hq), tx = up4_tap(x, wq);
+    for (int c = 0; c < channels; ++c)
+        out[(int64_t)b * so.b + (int64_t)c * so.c + (int64_t)y * so.h + x] =
+            up4_sample(in + (int64_t)b * sq.b + (int64_t)c * sq.c, sq.h, ty, tx, m0, m1);
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -583,14 +640,47 @@ using namespace vfi;
 extern "C" int vfi_flowprojection_forward(const float* input1, float* count, float* output, int batch, int h, int w,
                                            int fillhole, vfi_strides s1, vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !count || !output) return VFI_ERR_SHAPE;
-    return project_forward<false>(input1, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc, (hipStream_t)stream);
+    const ProjFlow flow{input1, s1, 0, 0, 1.0f, 1.0f};
+    return project_forward<false, false>(flow, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc, (hipStream_t)stream);
 }
 
 extern "C" int vfi_depthflowprojection_forward(const float* input1, const float* input2, float* count, float* output,
                                                 int batch, int h, int w, int fillhole, vfi_strides s1, vfi_strides s2,
                                                 vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !count || !output) return VFI_ERR_SHAPE;
-    return project_forward<true>(input1, input2, count, output, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
+    const ProjFlow flow{input1, s1, 0, 0, 1.0f, 1.0f};
+    return project_forward<true, false>(flow, input2, count, output, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
+}
+
+// ---- fused glue: the network's quarter-resolution flow goes straight into the splat
+extern "C" int vfi_flow_upsample4(const float* input, float* output, int batch, int channels, int hq, int wq,
+                                   float mul0, float mul1, vfi_strides sq, vfi_strides so, vfi_stream_t stream) {
+    if (batch <= 0 || channels <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !input || !output)
+        return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(flow_upsample4, pixel_grid(4 * wq, 4 * hq, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input, output, channels, hq, wq, mul0, mul1, sq, so);
+    return launch_status();
+}
+
+extern "C" int vfi_flowprojection_forward_up4(const float* flow_q, float* count, float* output, int batch, int hq, int wq,
+                                               float mul0, float mul1, int fillhole, vfi_strides sq, vfi_strides sc,
+                                               vfi_strides so, vfi_stream_t stream) {
+    if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !count || !output)
+        return VFI_ERR_SHAPE;
+    const ProjFlow flow{flow_q, sq, hq, wq, mul0, mul1};
+    return project_forward<false, true>(flow, nullptr, count, output, batch, 4 * hq, 4 * wq, fillhole, so, so, sc,
+                                        (hipStream_t)stream);
+}
+
+extern "C" int vfi_depthflowprojection_forward_up4(const float* flow_q, const float* input2, float* count, float* output,
+                                                    int batch, int hq, int wq, float mul0, float mul1, int fillhole,
+                                                    vfi_strides sq, vfi_strides s2, vfi_strides sc, vfi_strides so,
+                                                    vfi_stream_t stream) {
+    if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !input2 || !count || !output)
+        return VFI_ERR_SHAPE;
+    const ProjFlow flow{flow_q, sq, hq, wq, mul0, mul1};
+    return project_forward<true, true>(flow, input2, count, output, batch, 4 * hq, 4 * wq, fillhole, so, s2, sc,
+                                       (hipStream_t)stream);
 }
 
 extern "C" int vfi_flowprojection_backward(const float* input1, const float* count, const float* gradoutput,

@@ -1,0 +1,97 @@
+"""Host-side mirrors of the glue either side of the hot-path ops, on the fused entry
+points of libvfi_hip.so.  Same names and argument meaning as the reference's static helpers
+(`networks/DAIN_slowmotion.py:204-216, 301-335`, `PWCNet/PWCNet.py:159-199`,
+`demo_MiddleBury.py:280-318, 350-388`); inference only (no autograd)."""
+import math
+
+import torch
+
+from . import cabi
+
+
+def _check(err, what):
+    if err != 0:
+        raise RuntimeError("%s: the binding returned %d (shape / stride mismatch)" % (what, err))
+
+
+def forward_flownets_upsample(flow_q, div_flow, time_offsets):
+    """`forward_flownets` after the flow network: [div_flow * flow * t upsampled x4 for t in time_offsets]."""
+    b, c, hq, wq = flow_q.shape
+    outs = []
+    for t in time_offsets:
+        out = torch.empty((b, c, 4 * hq, 4 * wq), device=flow_q.device, dtype=torch.float32)
+        _check(cabi.flow_upsample4(flow_q, out, float(div_flow), float(t)), "flow_upsample4")
+        outs.append(out)
+    return outs
+
+
+def FlowProject_from_quarter(flow_q, div_flow, time_offsets, depth=None, fillhole=True):
+    """`forward_flownets` + `FlowProject` (inference: fillhole) without the full-resolution flows in between."""
+    b, _, hq, wq = flow_q.shape
+    outs = []
+    for t in time_offsets:
+        count = torch.empty((b, 1, 4 * hq, 4 * wq), device=flow_q.device, dtype=torch.float32)
+        out = torch.empty((b, 2, 4 * hq, 4 * wq), device=flow_q.device, dtype=torch.float32)
+        if depth is None:
+            err = cabi.flowprojection_forward_up4(flow_q, count, out, float(div_flow), float(t), int(fillhole))
+        else:
+            err = cabi.depthflowprojection_forward_up4(flow_q, depth, count, out, float(div_flow), float(t), int(fillhole))
+        _check(err, "flowprojection_forward_up4")
+        outs.append(out)
+    return outs
+
+
+def FilterInterpolate(ref0, ref2, offset, filter, filter_size2, time_offset):
+    """`DAIN.FilterInterpolate`: returns (ref0_offset*(1-t) + ref2_offset*t, ref0_offset, ref2_offset)."""
+    assert filter[0].size(1) == filter_size2
+    blend, out0, out2 = torch.empty_like(ref0), torch.empty_like(ref0), torch.empty_like(ref0)
+    _check(cabi.filterinterp_blend_forward(ref0, ref2, offset[0], offset[1], filter[0], filter[1], blend, out0, out2,
+                                           float(1.0 - time_offset), float(time_offset)), "filterinterp_blend_forward")
+    return blend, out0, out2
+
+
+def warp(x, flo, align_corners=True):
+    """`PWCDCNet.warp`."""
+    out = torch.empty_like(x)
+    _check(cabi.pwc_warp_forward(x, flo, out, align_corners), "pwc_warp_forward")
+    return out
+
+
+def padding_for(height, width):
+    """(left, right, top, bottom) of `demo_MiddleBury.py:294-310`: next multiple of 128, or 32 each side."""
+    def one(n):
+        if n != ((n >> 7) << 7):
+            total = (((n >> 7) + 1) << 7) - n
+            return int(total / 2), total - int(total / 2)
+        return 32, 32
+    left, right = one(width)
+    top, bottom = one(height)
+    return left, right, top, bottom
+
+
+def frames_to_padded(frames_u8):
+    """uint8 [B,h,w,3] on the GPU -> float32 [B,3,H,W] / 255 with replication padding; returns (tensor, padding)."""
+    b, h, w, _ = frames_u8.shape
+    left, right, top, bottom = padding_for(h, w)
+    out = torch.empty((b, 3, h + top + bottom, w + left + right), device=frames_u8.device, dtype=torch.float32)
+    _check(cabi.frame_u8_to_planar(frames_u8, out, left, right, top, bottom), "frame_u8_to_planar")
+    return out, (left, right, top, bottom)
+
+
+def padded_to_frames(y, height, width, padding):
+    """float32 [B,3,H,W] -> uint8 [B,height,width,3]: clip, crop, x255, round (`demo_MiddleBury.py:350-364`)."""
+    left, _, top, _ = padding
+    out = torch.empty((y.size(0), height, width, 3), device=y.device, dtype=torch.uint8)
+    _check(cabi.planar_to_frame_u8(y, out, top, left), "planar_to_frame_u8")
+    return out
+
+
+def interpolation_error_and_psnr(rec_u8, gt_u8):
+    """(mean |rec - gt|, PSNR in dB) of `demo_MiddleBury.py:370-381`; the sums are exact integers."""
+    sums = torch.zeros(2, device=rec_u8.device, dtype=torch.int64)
+    _check(cabi.frame_error_sums(rec_u8, gt_u8, sums), "frame_error_sums")
+    s_abs, s_sq = (int(v) for v in sums.cpu())
+    n = rec_u8.numel()
+    mse = s_sq / n
+    psnr = float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
+    return s_abs / n, psnr
