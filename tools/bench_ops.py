@@ -86,6 +86,65 @@ def main():
             ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
             print("corr thr=%-14d C=%-3d %4dx%-4d %8.4f ms" % (thr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
         cabi.lib().vfi_debug_correlation(256)
+    if "glue" in ops:
+        # the steps either side of the ops: fused launch vs the torch ops the reference uses
+        import torch.nn.functional as F
+        from vfidkr_amd import fused
+        flow_q = (torch.randn((1, 2, h // 4, w // 4), generator=gen) * 0.4).to(dev)
+        up = torch.empty((1, 2, h, w), device=dev)
+        timed(lambda: cabi.filterinterp_forward_ori(ctx, S.flow(1, h, w, 8.0, gen, "smooth").to(dev), filt, out196), 20)   # clocks up
+        ms = timed(lambda: cabi.flow_upsample4(flow_q, up, 20.0, 0.5), args.iters * 5)
+        ms_t = timed(lambda: F.interpolate(20.0 * flow_q * 0.5, scale_factor=4, mode="bilinear"), args.iters * 5)
+        print("glue  upsample4 x20 x t        %8.4f ms %8.1f GB/s | torch mul, mul, interpolate %8.4f ms"
+              % (ms, 8.5 * px / ms / 1e6, ms_t), flush=True)
+        ms_u = timed(lambda: (cabi.flow_upsample4(flow_q, up, 20.0, 0.5),
+                              cabi.depthflowprojection_forward(up, depth, count, proj, 1)), args.iters * 2)
+        ms_f = timed(lambda: cabi.depthflowprojection_forward_up4(flow_q, depth, count, proj, 20.0, 0.5, 1), args.iters * 2)
+        print("glue  upsample + dproj         %8.4f ms unfused | %8.4f ms fused (%5.1f GB/s of 16.5 B/px)"
+              % (ms_u, ms_f, 16.5 * px / ms_f / 1e6), flush=True)
+        flow = S.flow(1, h, w, 8.0 * w / 1984.0, gen, "smooth").to(dev)
+        flow2 = (-flow).contiguous()
+        frame2 = S.frames(1, h, w, gen).to(dev)
+        b_, o0, o2 = torch.empty_like(frame), torch.empty_like(frame), torch.empty_like(frame)
+
+        def unfused():
+            cabi.filterinterp_forward_ori(frame, flow, filt, o0)
+            cabi.filterinterp_forward_ori(frame2, flow2, filt, o2)
+            return o0 * 0.75 + o2 * 0.25
+        ms_u = timed(unfused, args.iters * 5)
+        ms_f = timed(lambda: cabi.filterinterp_blend_forward(frame, frame2, flow, flow2, filt, filt, b_, o0, o2, 0.75, 0.25),
+                     args.iters * 5)
+        print("glue  2 x FI(C=3) + blend      %8.4f ms unfused | %8.4f ms fused (%5.1f GB/s of 204 B/px)"
+              % (ms_u, ms_f, 204.0 * px / ms_f / 1e6), flush=True)
+        tot_f = tot_t = 0.0
+        for a, b2 in S.correlation_features(1, h, w, gen):
+            a, b2 = a.to(dev), b2.to(dev)
+            fl = (torch.randn((1, 2, a.shape[2], a.shape[3]), generator=gen) * 2).to(dev)
+            wo = torch.empty_like(b2)
+            tot_f += timed(lambda: cabi.pwc_warp_forward(b2, fl, wo, True), args.iters * 5)
+
+            def torch_warp():
+                B, C, H, W = b2.shape
+                xx = torch.arange(0, W, device=dev).view(1, 1, 1, W).expand(B, 1, H, W)
+                yy = torch.arange(0, H, device=dev).view(1, 1, H, 1).expand(B, 1, H, W)
+                vg = torch.cat((xx, yy), 1).float() + fl
+                vg = torch.stack((2.0 * vg[:, 0] / max(W - 1, 1) - 1.0, 2.0 * vg[:, 1] / max(H - 1, 1) - 1.0), 3)
+                o = F.grid_sample(b2, vg, align_corners=True)
+                m = F.grid_sample(torch.ones_like(b2), vg, align_corners=True)
+                m[m < 0.9999] = 0
+                m[m > 0] = 1
+                return o * m
+            tot_t += timed(torch_warp, args.iters * 5)
+        print("glue  PWC warp, 5 levels       %8.4f ms | torch grid_sample x2 + mask ops %8.4f ms" % (tot_f, tot_t), flush=True)
+        u8 = torch.randint(0, 256, (1, args.height, args.width, 3), dtype=torch.uint8, generator=gen).to(dev)
+        pad = fused.padding_for(args.height, args.width)
+        x = torch.empty((1, 3, h, w), device=dev)
+        ms1 = timed(lambda: cabi.frame_u8_to_planar(u8, x, *pad), args.iters * 5)
+        back = torch.empty_like(u8)
+        ms2 = timed(lambda: cabi.planar_to_frame_u8(x, back, pad[2], pad[0]), args.iters * 5)
+        sums = torch.zeros(2, dtype=torch.int64, device=dev)
+        ms3 = timed(lambda: cabi.frame_error_sums(u8, back, sums), args.iters * 5)
+        print("glue  frame in / out / error   %8.4f / %8.4f / %8.4f ms" % (ms1, ms2, ms3), flush=True)
     if "corr" in ops:
         tot_ms, tot_b = 0.0, 0.0
         for a, b in S.correlation_features(1, h, w, gen):

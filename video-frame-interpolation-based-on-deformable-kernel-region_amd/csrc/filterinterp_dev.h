@@ -49,6 +49,25 @@ __device__ __forceinline__ void fi4_channels_direct(const float* __restrict__ im
     }
 }
 
+// one channel of one valid pixel, fs == 4, from precomputed clamped row / column offsets (the body of
+// fi4_channels_direct's loop)
+__device__ __forceinline__ float fi4_value(const float* __restrict__ p, const unsigned (&ro)[4], const unsigned (&co)[4],
+                                           const float (&f)[16], float alpha, float beta) {
+    float a0 = p[ro[0] + co[0]], a1 = p[ro[0] + co[1]], a2 = p[ro[0] + co[2]], a3 = p[ro[0] + co[3]];
+    float TL = a0 * f[0];  TL = fmaf(a1, f[1], TL);
+    float TR = a2 * f[2];  TR = fmaf(a3, f[3], TR);
+    a0 = p[ro[1] + co[0]]; a1 = p[ro[1] + co[1]]; a2 = p[ro[1] + co[2]]; a3 = p[ro[1] + co[3]];
+    TL = fmaf(a0, f[4], TL);  TL = fmaf(a1, f[5], TL);
+    TR = fmaf(a2, f[6], TR);  TR = fmaf(a3, f[7], TR);
+    a0 = p[ro[2] + co[0]]; a1 = p[ro[2] + co[1]]; a2 = p[ro[2] + co[2]]; a3 = p[ro[2] + co[3]];
+    float BL = a0 * f[8];   BL = fmaf(a1, f[9], BL);
+    float BR = a2 * f[10];  BR = fmaf(a3, f[11], BR);
+    a0 = p[ro[3] + co[0]]; a1 = p[ro[3] + co[1]]; a2 = p[ro[3] + co[2]]; a3 = p[ro[3] + co[3]];
+    BL = fmaf(a0, f[12], BL);  BL = fmaf(a1, f[13], BL);
+    BR = fmaf(a2, f[14], BR);  BR = fmaf(a3, f[15], BR);
+    return blend4(alpha, beta, TL, TR, BL, BR);
+}
+
 // quadrant sums for a runtime filter size, rows outer / columns inner per quadrant
 __device__ __forceinline__ void quadrants_generic(const float* __restrict__ plane, const float* __restrict__ fpx,
                                                   int64_t fcs, int hs, int h, int w, int fs,

@@ -55,6 +55,33 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_blend_forward(
     const int64_t fo = (int64_t)b * sf.b + (int64_t)y * sf.h + x, ko = (int64_t)b * sk.b + (int64_t)y * sk.h + x;
     const FiSide a = fi_side(flow0 + fo, sf.c, x, y, w, h, fs), c2 = fi_side(flow2 + fo, sf.c, x, y, w, h, fs);
     const int64_t oo = (int64_t)b * so.b + (int64_t)y * so.h + x;
+    if (fs == 4) {
+        // taps, clamped rows and columns of both sides hoisted out of the channel loop
+        float f0[16], f2[16];
+        unsigned ro0[4], co0[4], ro2[4], co2[4];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            f0[k] = a.valid ? filt0[ko + (int64_t)k * sk.c] : 0.0f;
+            f2[k] = c2.valid ? filt2[ko + (int64_t)k * sk.c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ro0[k] = (unsigned)(clampi(a.T + k, 0, h - 1) * (int)sr.h);  co0[k] = (unsigned)clampi(a.L + k, 0, w - 1);
+            ro2[k] = (unsigned)(clampi(c2.T + k, 0, h - 1) * (int)sr.h); co2[k] = (unsigned)clampi(c2.L + k, 0, w - 1);
+        }
+        const unsigned self = (unsigned)(y * (int)sr.h + x);
+        for (int c = 0; c < channel; ++c) {
+            const float* p0 = ref0 + (int64_t)b * sr.b + (int64_t)c * sr.c;
+            const float* p2 = ref2 + (int64_t)b * sr.b + (int64_t)c * sr.c;
+            const float v0 = a.valid ? fi4_value(p0, ro0, co0, f0, a.alpha, a.beta) : p0[self];
+            const float v2 = c2.valid ? fi4_value(p2, ro2, co2, f2, c2.alpha, c2.beta) : p2[self];
+            if (out0) out0[oo + (int64_t)c * so.c] = v0;
+            if (out2) out2[oo + (int64_t)c * so.c] = v2;
+            const float q0 = v0 * w0, q2 = v2 * w2;
+            blend[oo + (int64_t)c * so.c] = q0 + q2;
+        }
+        return;
+    }
     for (int c = 0; c < channel; ++c) {
         const float v0 = fi_side_value(a, ref0 + (int64_t)b * sr.b + (int64_t)c * sr.c, filt0 + ko, sk.c, (int)sr.h, h, w, fs, x, y);
         const float v2 = fi_side_value(c2, ref2 + (int64_t)b * sr.b + (int64_t)c * sr.c, filt2 + ko, sk.c, (int)sr.h, h, w, fs, x, y);
@@ -62,6 +89,20 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_blend_forward(
         if (out2) out2[oo + (int64_t)c * so.c] = v2;
         const float p0 = v0 * w0, p2 = v2 * w2;
         blend[oo + (int64_t)c * so.c] = p0 + p2;
+    }
+}
+
+// blend = out0 * w0 + out2 * w2, the two products rounded separately
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_blend_only(
+    const float* __restrict__ out0, const float* __restrict__ out2, float* __restrict__ blend, int channel, int h, int w,
+    float w0, float w2, vfi_strides so) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int64_t oo = (int64_t)blockIdx.z * so.b + (int64_t)y * so.h + x;
+    for (int c = 0; c < channel; ++c) {
+        const float q0 = out0[oo + (int64_t)c * so.c] * w0, q2 = out2[oo + (int64_t)c * so.c] * w2;
+        blend[oo + (int64_t)c * so.c] = q0 + q2;
     }
 }
 
@@ -147,11 +188,28 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void planar_to_frame_u8(
     }
 }
 
-// sums[0] += sum |a - b|, sums[1] += sum (a - b)^2 over n bytes: exact integers
+// sums[0] += sum |a - b|, sums[1] += sum (a - b)^2 over n bytes: exact integers.  16 bytes per load,
+// one pair of atomics per workgroup.
 __global__ __launch_bounds__(256) void frame_error_sums(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
                                                         int64_t n, unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long part[2][4];
     unsigned long long sa = 0ull, sq = 0ull;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool wide = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const int64_t n16 = wide ? n >> 4 : 0;
+    for (int64_t i = tid; i < n16; i += stride) {
+        const uint4 va = reinterpret_cast<const uint4*>(a)[i], vb = reinterpret_cast<const uint4*>(b)[i];
+        const unsigned wa[4] = { va.x, va.y, va.z, va.w }, wb[4] = { vb.x, vb.y, vb.z, vb.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int s = 0; s < 32; s += 8) {
+                const int d = (int)((wa[k] >> s) & 255u) - (int)((wb[k] >> s) & 255u);
+                sa += (unsigned)(d < 0 ? -d : d);
+                sq += (unsigned)(d * d);
+            }
+    }
+    for (int64_t i = (n16 << 4) + tid; i < n; i += stride) {
         const int d = (int)a[i] - (int)b[i];
         sa += (unsigned)(d < 0 ? -d : d);
         sq += (unsigned)(d * d);
@@ -161,10 +219,10 @@ __global__ __launch_bounds__(256) void frame_error_sums(const unsigned char* __r
         sa += __shfl_xor(sa, o);
         sq += __shfl_xor(sq, o);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&sums[0], sa);
-        atomicAdd(&sums[1], sq);
-    }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = sa; part[1][threadIdx.x >> 6] = sq; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(&sums[threadIdx.x], part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
 }
 
 }  // namespace vfi
@@ -179,6 +237,17 @@ extern "C" int vfi_filterinterp_blend_forward(const float* ref0, const float* re
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
     if (!ref0 || !ref2 || !flow0 || !flow2 || !filt0 || !filt2 || !blend) return VFI_ERR_SHAPE;
     const int fs = (int)sqrtf((float)filter_channels);
+    if (filter_channels == 16 && out0 && out2 && s_out.b == s_ref.b && s_out.c == s_ref.c && s_out.h == s_ref.h) {
+        // the LDS-staged forward per side (faster than the direct gather even at C = 3; it writes with the
+        // input's strides), then the blend
+        int err = vfi_filterinterp_forward_ori(ref0, flow0, filt0, out0, batch, channel, h, w, 16, s_ref, s_flow, s_filt, stream);
+        if (err != VFI_OK) return err;
+        err = vfi_filterinterp_forward_ori(ref2, flow2, filt2, out2, batch, channel, h, w, 16, s_ref, s_flow, s_filt, stream);
+        if (err != VFI_OK) return err;
+        hipLaunchKernelGGL(fi_blend_only, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, out0,
+                           out2, blend, channel, h, w, w0, w2, s_out);
+        return launch_status();
+    }
     hipLaunchKernelGGL(fi_blend_forward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, ref0,
                        ref2, flow0, flow2, filt0, filt2, blend, out0, out2, channel, h, w, fs, w0, w2, s_ref, s_flow,
                        s_filt, s_out);
@@ -215,8 +284,8 @@ extern "C" int vfi_planar_to_frame_u8(const float* src, unsigned char* dst_hwc, 
 extern "C" int vfi_frame_error_sums(const unsigned char* a, const unsigned char* b, int64_t n, unsigned long long* sums,
                                      vfi_stream_t stream) {
     if (n <= 0 || !a || !b || !sums) return VFI_ERR_SHAPE;
-    const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    hipLaunchKernelGGL(frame_error_sums, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+    const int64_t blocks = (n + 256 * 64 - 1) / (256 * 64);
+    hipLaunchKernelGGL(frame_error_sums, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream,
                        a, b, n, sums);
     return launch_status();
 }
