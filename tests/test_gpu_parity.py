@@ -796,3 +796,42 @@ def test_full_size_1080p(torch_mod, cabi, oracle):
     onehot = torch.zeros_like(gk)
     onehot[:, 5] = 1
     assert torch.equal(run_fi(torch, cabi, gc, torch.zeros_like(gf), onehot), gc)
+
+
+@pytest.mark.parametrize("raw", [(256, 448), (480, 640), (2160, 3840)])
+def test_other_baseline_sizes(torch_mod, cabi, oracle, raw):
+    """cfg1/cfg4 (256x448 -> 320x512), cfg2 (480x640 -> 512x704), cfg5 (4K -> 2176x3904): the frame-level ops
+    on the whole padded frame; LDS == direct, oracle on the frame, projection count exact, the fused
+    quarter-flow projection == the unfused pair."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import fused, synthetic as S
+    H, W = S.padded_size(*raw)
+    left, right, top, bottom = fused.padding_for(*raw)
+    assert (H, W) == (raw[0] + top + bottom, raw[1] + left + right)
+    gen = S.generator()
+    frame, filt = S.frames(1, H, W, gen), S.filters(1, H, W, gen)
+    flow = S.flow(1, H, W, 8.0 * W / 1984.0, gen, "smooth")
+    gi, gf, gk = frame.cuda(), flow.cuda(), filt.cuda()
+    a = run_fi(torch, cabi, gi, gf, gk, direct=False)
+    assert torch.equal(a, run_fi(torch, cabi, gi, gf, gk, direct=True))
+    assert np.array_equal(cpu(a), oracle.filterinterp_ori_fwd(frame.numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8))
+    count = torch.full((1, 1, H, W), float("nan"), device="cuda:0")
+    out = torch.full((1, 2, H, W), float("nan"), device="cuda:0")
+    assert cabi.flowprojection_forward(gf, count, out, 1) == 0
+    rout, rcount = oracle.flowproj_fwd(flow.numpy(), 1)
+    assert np.array_equal(cpu(count), rcount) and np.abs(cpu(out) - rout).max() <= 1e-4
+    flow_q = (torch.randn((1, 2, H // 4, W // 4), generator=gen) * 0.3).cuda()
+    full = torch.empty((1, 2, H, W), device="cuda:0")
+    assert cabi.flow_upsample4(flow_q, full, 20.0, 0.5) == 0
+    c2, o2 = torch.empty_like(count), torch.empty_like(out)
+    assert cabi.flowprojection_forward(full, count, out, 1) == 0
+    assert cabi.flowprojection_forward_up4(flow_q, c2, o2, 20.0, 0.5, 1) == 0
+    assert torch.equal(c2, count) and torch.equal(o2, out)
+    if raw[0] >= 2160:
+        # a 64-channel slice of the 4K context tensor (6.7 GB at C = 196): 64-bit plane offsets
+        ctx = S.context(1, 64, H, W, gen).cuda()
+        a = run_fi(torch, cabi, ctx, gf, gk, direct=False)
+        assert torch.equal(a, run_fi(torch, cabi, ctx, gf, gk, direct=True))
+        ref = oracle.filterinterp_ori_fwd(ctx[:, [0, 63]].cpu().numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8)
+        assert np.array_equal(cpu(a[:, [0, 63]]), ref)

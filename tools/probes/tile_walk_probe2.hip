@@ -46,9 +46,12 @@ __global__ __launch_bounds__(512) void walk(const float* __restrict__ in, float*
 }
 
 // float4 per lane: tile (64*4) x TH... each thread 4 consecutive pixels of PX rows
-template <int TH, int UNROLL, int NT>
+// LDSPAD > 0: a dummy LDS allocation that caps the workgroups per CU (occupancy experiment)
+template <int TH, int UNROLL, int NT, int LDSPAD = 0>
 __global__ __launch_bounds__(512) void walk4(const float4* __restrict__ in, float4* __restrict__ out, int C, int H, int W4,
                                              int tiles_x) {
+    __shared__ float pad[LDSPAD > 0 ? LDSPAD : 1];
+    if (LDSPAD > 0 && C < 0) pad[threadIdx.x] = 1.0f;
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     constexpr int PX = TH / 8;
@@ -127,6 +130,14 @@ int main() {
         printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u2", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
         ms = timeit([&] { hipLaunchKernelGGL((walk4<16, 1, 0>), dim3(txs * ((H + 15) / 16)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
         printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x16 u1", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 1, 0, 16000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
+        printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u1, 2 workgroups per CU (16 waves)", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 2, 0, 16000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
+        printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u2, 2 workgroups per CU", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 4, 0, 16000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
+        printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u4, 2 workgroups per CU", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 1, 0, 10000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
+        printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u1, 4 workgroups per CU (32 waves, LDS 40K)", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
     }
     return 0;
 }
