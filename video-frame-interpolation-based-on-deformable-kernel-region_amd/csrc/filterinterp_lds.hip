@@ -62,16 +62,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 typedef __attribute__((address_space(3))) void* fi_lptr_t;
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ int wave_min(int v) { return wave_min_i32(v); }
+__device__ __forceinline__ int wave_max(int v) { return wave_max_i32(v); }
 
 struct FiWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
 struct FiPixel {

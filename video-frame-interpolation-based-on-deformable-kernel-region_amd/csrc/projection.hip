@@ -34,13 +34,13 @@
 //
 // Accumulation in B is 64-bit fixed point (ds_add_u64): on gfx950 an LDS float atomic add
 // costs ~170 cycles per wave instruction (measured, tools/probes/lds_atomic_probe.hip), an
-// integer one ~6.  Every addend is scaled by a power of two chosen per call from the
-// largest |addend| (found by A) so that no cell can overflow, rounded to an integer and
-// summed exactly; the integer sum is converted back to float once.  The result is the
-// correctly rounded sum (the reference's fp32 atomic sum carries one rounding per addend,
-// in arrival order), independent of summation order and therefore reproducible bit for bit
-// from run to run.  It agrees with any fp32 summation order to rounding; addends that are
-// multiples of 2^-k (k < ~30) sum exactly in both.  count of FlowProjection is exact.
+// integer one ~6.  Every addend is scaled by a power of two chosen per output tile from the
+// largest |addend| that reaches it (found by A), rounded to a 32-bit integer (an error below
+// 2^-31 of that largest addend) and summed exactly in int64; the sum is converted back to
+// float once.  The result does not depend on the summation order, so it is reproducible bit
+// for bit from run to run (the reference's fp32 atomic sum carries one rounding per addend, in
+// arrival order), and it agrees with any fp32 summation order to rounding; addends that are
+// multiples of 2^-k (k < ~20) sum exactly in both.  count of FlowProjection is exact.
 #include "vfi_common.h"
 
 #include <limits.h>
@@ -152,16 +152,8 @@ __device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float*
     return s;
 }
 
-__device__ __forceinline__ int wmin(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wmax(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ int wmin(int v) { return wave_min_i32(v); }
+__device__ __forceinline__ int wmax(int v) { return wave_max_i32(v); }
 
 // A: bin source row segments into the lists of the output tiles they reach.  A workgroup covers the
 // 64x16 tile of its index: its 16 row segments first find their target rectangles (in tiles), then
@@ -260,16 +252,16 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     const int nsrc = min(rec[0], PROJ_LIST_CAP);
     const int vb = rec[PROJ_REC_VMAX], cb = rec[PROJ_REC_CMAX];
     const bool fallback = ws[0] == serial;
-    // fixed-point scales: addend * 2^k rounded to int64.  A cell of this tile receives at most
-    // 4 * h * w addends (nb bits), all from the segments on this tile's list, each below 2^e with e
-    // from the list's maxima: k = 62 - nb - e keeps every sum inside int64.  (Per output tile, so no
-    // global reduction is needed; a sum only ever mixes addends of one scale.)
-    const int nb = 34 - __clz((unsigned)max(1, (int)min((int64_t)INT_MAX, (int64_t)g.h * g.w)));   // >= log2(4*h*w)
+    // fixed-point scales: addend * 2^k rounded to a 32-bit integer, summed in int64.  Every addend that
+    // reaches this tile is below 2^e with e from its list's maxima, so k = 30 - e keeps the product
+    // inside int32 (one v_rndne + v_cvt instead of an emulated float -> int64), and a cell can take
+    // 2^32 addends before the int64 sum overflows.  (Per output tile, so no global reduction is needed;
+    // a sum only ever mixes addends of one scale.)
     int ev = 0, ec = 0;
     (void)frexpf(__int_as_float(vb), &ev);
     (void)frexpf(__int_as_float(cb), &ec);
     // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
-    const int kv = max(-100, min(100, 62 - nb - ev)), kc = max(-100, min(100, 62 - nb - ec));
+    const int kv = max(-100, min(100, 30 - ev)), kc = max(-100, min(100, 30 - ec));
     const float sv = ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);     // exact powers of two
     __syncthreads();                                        // every thread has read the record ...
     if (tid < 3) rec[tid] = 0;                              // ... leave it empty for the next call
@@ -314,11 +306,11 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
         const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
         const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
         const bool inT = (unsigned)ty < PROJ_TH, inB = (unsigned)by < PROJ_TH;
-        // addend * 2^k is exact in float (power-of-two scale, |product| < 2^40); two's complement:
-        // adding the unsigned image of a negative int64 subtracts
-        const unsigned long long qx = (unsigned long long)__float2ll_rn(s.ax * sv);
-        const unsigned long long qy = (unsigned long long)__float2ll_rn(s.ay * sv);
-        const unsigned long long qc = (unsigned long long)__float2ll_rn(s.ac * scn);
+        // addend * 2^k is exact in float (power-of-two scale) and below 2^30 in magnitude; two's
+        // complement: adding the unsigned image of a negative int64 subtracts
+        const unsigned long long qx = (unsigned long long)(long long)__float2int_rn(s.ax * sv);
+        const unsigned long long qy = (unsigned long long)(long long)__float2int_rn(s.ay * sv);
+        const unsigned long long qc = (unsigned long long)(long long)__float2int_rn(s.ac * scn);
         if (inT && inL) { atomicAdd(&acc[0][ty][lx], qx); atomicAdd(&acc[1][ty][lx], qy); atomicAdd(&acc[2][ty][lx], qc); }
         if (inT && inR) { atomicAdd(&acc[0][ty][rx], qx); atomicAdd(&acc[1][ty][rx], qy); atomicAdd(&acc[2][ty][rx], qc); }
         if (inB && inL) { atomicAdd(&acc[0][by][lx], qx); atomicAdd(&acc[1][by][lx], qy); atomicAdd(&acc[2][by][lx], qc); }

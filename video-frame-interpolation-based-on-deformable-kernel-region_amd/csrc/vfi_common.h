@@ -43,6 +43,22 @@ __device__ __forceinline__ bool fi_valid(float fx, float fy, float x2, float y2,
            fabsf(fx) < (float)w / 2.0f && fabsf(fy) < (float)h / 2.0f;
 }
 
+// Wave-wide min / max as six DPP steps at VALU rate (prefix within each row of 16 lanes, then
+// row_bcast:15 and row_bcast:31 carry the row results to lane 63), read back as a scalar.  The
+// __shfl_xor butterfly compiles to six dependent ds_bpermute_b32, each an LDS round trip.
+#define VFI_DPP_STEP(OP, CTRL, ROWMASK) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ int wave_min_i32(int v) {
+    VFI_DPP_STEP(min, 0x111, 0xf); VFI_DPP_STEP(min, 0x112, 0xf); VFI_DPP_STEP(min, 0x114, 0xf);
+    VFI_DPP_STEP(min, 0x118, 0xf); VFI_DPP_STEP(min, 0x142, 0xa); VFI_DPP_STEP(min, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    VFI_DPP_STEP(max, 0x111, 0xf); VFI_DPP_STEP(max, 0x112, 0xf); VFI_DPP_STEP(max, 0x114, 0xf);
+    VFI_DPP_STEP(max, 0x118, 0xf); VFI_DPP_STEP(max, 0x142, 0xa); VFI_DPP_STEP(max, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#undef VFI_DPP_STEP
+
 inline dim3 pixel_grid(int w, int h, int batch) {
     return dim3((unsigned)((w + VFI_TX - 1) / VFI_TX), (unsigned)((h + VFI_TY - 1) / VFI_TY), (unsigned)batch);
 }
