@@ -54,6 +54,7 @@ namespace vfi {
 #define PROJ_TH 16
 #define PROJ_THREADS 256
 #define PROJ_LIST_CAP 252           // source row segments per output tile before the fallback kicks in
+#define PROJ_SEG_SHIFT 12           // segment id = (batch * h + row) << 12 | tile column
 
 // workspace "words" (32-bit): [0] serial of the last call whose lists overflowed; from word 16 one
 // record per output tile: [0] list length, [1] / [2] bit patterns of the largest |value addend| /
@@ -106,37 +107,76 @@ __device__ __forceinline__ UpTap up4_tap(int dst, int in_size) {
     t.l0 = 1.0f - t.l1;
     return t;
 }
-// one channel at (x, y) of the upsampled (m0 * plane) * m1; fused as nvcc fuses ATen's expression
-__device__ __forceinline__ float up4_sample(const float* __restrict__ plane, int64_t hs, const UpTap& ty, const UpTap& tx,
-                                            float m0, float m1) {
-    const float p00 = (m0 * plane[(int64_t)ty.i0 * hs + tx.i0]) * m1, p01 = (m0 * plane[(int64_t)ty.i0 * hs + tx.i1]) * m1;
-    const float p10 = (m0 * plane[(int64_t)ty.i1 * hs + tx.i0]) * m1, p11 = (m0 * plane[(int64_t)ty.i1 * hs + tx.i1]) * m1;
+// one channel of the upsampled (m0 * plane) * m1 from its four taps; fused as nvcc fuses ATen's expression
+__device__ __forceinline__ float up4_blend(float q00, float q01, float q10, float q11, const UpTap& ty, const UpTap& tx,
+                                           float m0, float m1) {
+    const float p00 = (m0 * q00) * m1, p01 = (m0 * q01) * m1, p10 = (m0 * q10) * m1, p11 = (m0 * q11) * m1;
     const float t0 = fmaf(tx.l1, p01, tx.l0 * p00);
     const float t1 = fmaf(tx.l1, p11, tx.l0 * p10);
     return fmaf(ty.l1, t1, ty.l0 * t0);
 }
+__device__ __forceinline__ float up4_sample(const float* __restrict__ plane, int64_t hs, const UpTap& ty, const UpTap& tx,
+                                            float m0, float m1) {
+    return up4_blend(plane[(int64_t)ty.i0 * hs + tx.i0], plane[(int64_t)ty.i0 * hs + tx.i1],
+                     plane[(int64_t)ty.i1 * hs + tx.i0], plane[(int64_t)ty.i1 * hs + tx.i1], ty, tx, m0, m1);
+}
+
+// A source pixel in two steps, so that a caller can have the loads of the next pixel in flight while
+// it works on the current one: proj_load only issues loads (raw values, no arithmetic on them),
+// proj_make turns them into the splat.
+struct ProjRaw {
+    bool in;                // inside the frame
+    int x, y;
+    float v[8];             // !UP: v[0] = fx, v[1] = fy;  UP: the 2 x 4 quarter-resolution taps
+    float d;                // depth weight (DEPTH only)
+};
 
 template <bool DEPTH, bool UP>
-__device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float* __restrict__ in2,
-                                                 int b, int x, int y, int h, int w, vfi_strides s2) {
+__device__ __forceinline__ ProjRaw proj_load(const ProjFlow& f, const float* __restrict__ in2,
+                                             int b, int x, int y, int h, int w, vfi_strides s2) {
+    ProjRaw r;
+    r.in = x < w && y < h;
+    r.x = x; r.y = y;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = 0.0f;
+    r.d = 0.0f;
+    if (!r.in) return r;
+    if constexpr (UP) {
+        const UpTap ty = up4_tap(y, f.hq), tx = up4_tap(x, f.wq);
+        const float* q = f.p + (int64_t)b * f.s.b;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* plane = q + (int64_t)c * f.s.c;
+            r.v[4 * c + 0] = plane[(int64_t)ty.i0 * f.s.h + tx.i0]; r.v[4 * c + 1] = plane[(int64_t)ty.i0 * f.s.h + tx.i1];
+            r.v[4 * c + 2] = plane[(int64_t)ty.i1 * f.s.h + tx.i0]; r.v[4 * c + 3] = plane[(int64_t)ty.i1 * f.s.h + tx.i1];
+        }
+    } else {
+        const float* flow = f.p + (int64_t)b * f.s.b + (int64_t)y * f.s.h + x;
+        r.v[0] = flow[0];
+        r.v[1] = flow[f.s.c];
+    }
+    if constexpr (DEPTH) r.d = in2[(int64_t)b * s2.b + (int64_t)y * s2.h + x];
+    return r;
+}
+
+template <bool DEPTH, bool UP>
+__device__ __forceinline__ ProjSplat proj_make(const ProjFlow& f, const ProjRaw& r, int h, int w) {
     ProjSplat s;
     s.valid = false;
     s.L = s.T = s.R = s.Bm = 0;
     s.ax = s.ay = s.ac = 0.0f;
-    if (x >= w || y >= h) return s;
+    if (!r.in) return s;
     float fx, fy;
     if constexpr (UP) {
-        const UpTap ty = up4_tap(y, f.hq), tx = up4_tap(x, f.wq);
-        const float* q = f.p + (int64_t)b * f.s.b;
-        fx = up4_sample(q, f.s.h, ty, tx, f.m0, f.m1);
-        fy = up4_sample(q + f.s.c, f.s.h, ty, tx, f.m0, f.m1);
+        const UpTap ty = up4_tap(r.y, f.hq), tx = up4_tap(r.x, f.wq);
+        fx = up4_blend(r.v[0], r.v[1], r.v[2], r.v[3], ty, tx, f.m0, f.m1);
+        fy = up4_blend(r.v[4], r.v[5], r.v[6], r.v[7], ty, tx, f.m0, f.m1);
     } else {
-        const float* flow = f.p + (int64_t)b * f.s.b + (int64_t)y * f.s.h + x;
-        fx = flow[0];
-        fy = flow[f.s.c];
+        fx = r.v[0];
+        fy = r.v[1];
     }
-    const float x2 = (float)x + fx;
-    const float y2 = (float)y + fy;
+    const float x2 = (float)r.x + fx;
+    const float y2 = (float)r.y + fy;
     if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1))) return s;
     s.valid = true;
     s.L = (int)x2;
@@ -144,12 +184,17 @@ __device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float*
     s.R = min(s.L + 1, w - 1);
     s.Bm = min(s.T + 1, h - 1);
     if constexpr (DEPTH) {
-        const float d = in2[(int64_t)b * s2.b + (int64_t)y * s2.h + x];
-        s.ax = -d * fx; s.ay = -d * fy; s.ac = d;       // depthflowprojection_cuda_kernel.cu:74-91
+        s.ax = -r.d * fx; s.ay = -r.d * fy; s.ac = r.d;     // depthflowprojection_cuda_kernel.cu:74-91
     } else {
-        s.ax = -fx; s.ay = -fy; s.ac = 1.0f;            // flowprojection_cuda_kernel.cu:75-88
+        s.ax = -fx; s.ay = -fy; s.ac = 1.0f;                // flowprojection_cuda_kernel.cu:75-88
     }
     return s;
+}
+
+template <bool DEPTH, bool UP>
+__device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float* __restrict__ in2,
+                                                 int b, int x, int y, int h, int w, vfi_strides s2) {
+    return proj_make<DEPTH, UP>(f, proj_load<DEPTH, UP>(f, in2, b, x, y, h, w, s2), h, w);
 }
 
 __device__ __forceinline__ int wmin(int v) { return wave_min_i32(v); }
@@ -210,7 +255,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
     if (cx0 == INT_MAX) return;                             // nothing of this tile lands in the frame
     const int nx = cx1 - cx0 + 1, ncand = nx * (cy1 - cy0 + 1);
     const int vmax = tmax[0], cmax = tmax[1];
-    const int seg0 = (b * g.h + tyi * PROJ_TH) * g.tiles_x + txi;
+    // segment id = global row << 12 | tile column: the gather splits it with a shift and a mask
+    const int seg0 = ((b * g.h + tyi * PROJ_TH) << PROJ_SEG_SHIFT) | txi;
     for (int c = tid; c < ncand; c += PROJ_THREADS) {
         const int ctx = cx0 + c % nx, cty = cy0 + c / nx;
         unsigned rows = 0u;                                 // which of the 16 segments reach this output tile
@@ -225,7 +271,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
         while (rows) {
             const int r = __ffs((int)rows) - 1;
             rows &= rows - 1u;
-            rec[PROJ_REC_IDS + slot++] = seg0 + r * g.tiles_x;
+            rec[PROJ_REC_IDS + slot++] = seg0 + (r << PROJ_SEG_SHIFT);
         }
         if (vmax > __hip_atomic_load(&rec[PROJ_REC_VMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&rec[PROJ_REC_VMAX], vmax);
@@ -294,14 +340,16 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     const int mine = (nsrc > wave) ? (nsrc - wave + PROJ_THREADS / 64 - 1) / (PROJ_THREADS / 64) : 0;   // <= 63
     const int ids = (lane < mine) ? list[wave + lane * (PROJ_THREADS / 64)] : 0;
     auto fetch = [&](int j) {
-        const int seg = __shfl(ids, j);
-        return proj_source<DEPTH, UP>(flow, in2, b, (seg % g.tiles_x) * PROJ_TW + lane, seg / g.tiles_x - b * g.h,
-                                      g.h, g.w, s2);
+        // wave-uniform: the row arithmetic of the loads stays on the scalar unit
+        const int seg = __builtin_amdgcn_readlane(ids, j);
+        return proj_load<DEPTH, UP>(flow, in2, b, (seg & ((1 << PROJ_SEG_SHIFT) - 1)) * PROJ_TW + lane,
+                                    (seg >> PROJ_SEG_SHIFT) - b * g.h, g.h, g.w, s2);
     };
-    ProjSplat nxt = fetch(0);                               // lane 0 holds 0 when the wave has no entry: harmless
+    ProjRaw nxt = fetch(0);                                 // lane 0 holds 0 when the wave has no entry: harmless
     for (int j = 0; j < mine; ++j) {
-        const ProjSplat s = nxt;
-        if (j + 1 < mine) nxt = fetch(j + 1);
+        const ProjRaw cur = nxt;
+        if (j + 1 < mine) nxt = fetch(j + 1);               // in flight while this segment is accumulated
+        const ProjSplat s = proj_make<DEPTH, UP>(flow, cur, g.h, g.w);
         // cells of this output tile only; R == L / Bm == T at the far edges add twice (:72-73)
         const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
         const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
@@ -582,7 +630,8 @@ static int project_forward(const ProjFlow& flow, const float* in2, float* count,
     g.tiles_x = (w + PROJ_TW - 1) / PROJ_TW;
     g.tiles_y = (h + PROJ_TH - 1) / PROJ_TH;
     const int64_t nt = (int64_t)g.tiles_x * g.tiles_y * batch;
-    if (nt > (1 << 24)) return VFI_ERR_SHAPE;
+    if (nt > (1 << 24) || g.tiles_x > (1 << PROJ_SEG_SHIFT) || (int64_t)batch * h >= (1 << (31 - PROJ_SEG_SHIFT)))
+        return VFI_ERR_SHAPE;
     g.ntiles = (int)nt;
     g.rmw = (w + 31) / 32;
     g.cmw = (g.tiles_y * PROJ_TH + 31) / 32;                // whole tiles: B ORs 16-bit halves
