@@ -207,7 +207,7 @@ __device__ __forceinline__ int wmax(int v) { return wave_max_i32(v); }
 // measured 4x slower: the round trips serialise).
 #define PROJ_BIN_CAND 64            // candidate output tiles per source tile handled by the fast path
 template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
+__global__ __launch_bounds__(PROJ_THREADS, 8) void proj_bin(
     ProjFlow flow, const float* __restrict__ in2, ProjGeom g, vfi_strides s2,
     int* __restrict__ ws, int* __restrict__ bits, int serial) {
     __shared__ int rect[PROJ_TH][4];                        // per row segment: tx0, ty0, tx1, ty1 (tx0 < 0: none)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
     __syncthreads();
     // union rectangle of the tile's segments
     int cx0 = INT_MAX, cy0 = INT_MAX, cx1 = INT_MIN, cy1 = INT_MIN;
-#pragma unroll
+#pragma unroll 2
     for (int r = 0; r < PROJ_TH; ++r)
         if (rect[r][0] >= 0) {
             cx0 = min(cx0, rect[r][0]); cy0 = min(cy0, rect[r][1]);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bin(
     for (int c = tid; c < ncand; c += PROJ_THREADS) {
         const int ctx = cx0 + c % nx, cty = cy0 + c / nx;
         unsigned rows = 0u;                                 // which of the 16 segments reach this output tile
-#pragma unroll
+#pragma unroll 2
         for (int r = 0; r < PROJ_TH; ++r)
             if (rect[r][0] >= 0 && ctx >= rect[r][0] && ctx <= rect[r][2] && cty >= rect[r][1] && cty <= rect[r][3])
                 rows |= 1u << r;
