@@ -64,6 +64,16 @@ int vfi_filterinterp_backward_ori(const float* input1, const float* input2, cons
                                   vfi_strides s1, vfi_strides s2, vfi_strides s3,
                                   vfi_stream_t stream);
 
+/* fp16 STORAGE, fp32 arithmetic (BASELINE.json configs[2]): input1 and output are IEEE
+ * half tensors (strides in half elements), flow and filter stay float32.  The result is the fp32
+ * result of the function above on the widened inputs, rounded to half once; the LDS-staged path
+ * (filter_channels == 16) sums the 16 products in one chain and agrees with that to fp16 rounding. */
+int vfi_filterinterp_forward_ori_f16(const void* input1_half, const float* input2, const float* input3,
+                                     void* output_half,
+                                     int batch, int channel, int h, int w, int filter_channels,
+                                     vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                     vfi_stream_t stream);
+
 /* deformable-kernel variants (filterinterpolation_cuda.cc:11-92, 191-272, 374-447).
  * variant: 0 = FilterInterpolationLayer_gpu_forward (4 inputs, fs in {4,6}),
  *          1 = ..._forward_deforconv, 2 = ..._forward_nofilterwithdeforconv

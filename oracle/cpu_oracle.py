@@ -284,3 +284,9 @@ def frame_error(rec_u8, gt_u8):
     err = float(np.mean(np.abs(diff - 128.0)))
     mse = float(np.mean((diff - 128.0) ** 2))
     return err, (float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse)))
+
+
+def filterinterp_ori_fwd_f16(img16, flow, filt, fmad=1, nthreads=1):
+    """fp16 storage, fp32 arithmetic: the fp32 op on the widened image, rounded to half once."""
+    assert img16.dtype == np.float16
+    return filterinterp_ori_fwd(img16.astype(np.float32), flow, filt, fmad, nthreads).astype(np.float16)

@@ -206,6 +206,73 @@ def test_deformable_backward(torch_mod, cabi, oracle, variant, fs):
         assert not cpu(go)[0, :, 3, 3].any() and not cpu(g2)[0, :, 3, 3].any()
 
 
+# ------------------------------------------------------------------ fp16 storage (BASELINE configs[2])
+
+def gpu16(torch, a):
+    t = torch.empty(a.shape, dtype=torch.float16, device="cuda:0")
+    t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return t
+
+
+# the staged kernel sums the 16 products in one chain: equal to the reference order to fp16 rounding
+F16_TOL = 2e-3
+
+
+@pytest.mark.parametrize("B,C,H,W,fs", [(1, 3, 32, 48, 4), (2, 5, 40, 72, 4), (1, 3, 17, 130, 4), (1, 1, 1, 1, 4),
+                                         (1, 2, 3, 5, 4), (1, 196, 20, 70, 4), (1, 3, 24, 40, 5), (1, 2, 9, 7, 2)])
+@pytest.mark.parametrize("flow_kind", ["smooth", "uniform1", "wild", "zero", "border"])
+def test_filterinterp_f16_storage(torch_mod, cabi, oracle, B, C, H, W, fs, flow_kind):
+    torch = torch_mod
+    rng = np.random.default_rng(B * 7 + C * 3 + H + W + fs)
+    img = rng.random((B, C, H, W), dtype=f32).astype(np.float16)
+    filt = (rng.random((B, fs * fs, H, W), dtype=f32) * f32(4.0 / (fs * fs))).astype(f32)      # results stay near [0, 1]
+    if flow_kind == "smooth":
+        flow = smooth_flow(rng, B, H, W, 3.0) if H > 1 else np.zeros((B, 2, H, W), f32)
+    elif flow_kind == "uniform1":
+        flow = rng.uniform(-1, 1, (B, 2, H, W)).astype(f32)
+    elif flow_kind == "wild":
+        flow = rng.uniform(-W / 2, W / 2, (B, 2, H, W)).astype(f32)
+    elif flow_kind == "zero":
+        flow = np.zeros((B, 2, H, W), f32)
+    else:
+        flow = np.zeros((B, 2, H, W), f32)
+        flow[:, 0] = (W - 1) - np.arange(W)[None, None, :]
+        flow[:, 1] = (H - 1) - np.arange(H)[None, :, None]
+        flow[:, 0, 1::2] = -np.arange(W)[None, None, :]
+    ref = oracle.filterinterp_ori_fwd_f16(img, flow, filt, fmad=1)
+    for direct in (True, False):
+        out = torch.full((B, C, H, W), float("nan"), dtype=torch.float16, device="cuda:0")
+        assert cabi.filterinterp_forward_ori_f16(gpu16(torch, img), gpu(torch, flow), gpu(torch, filt), out, direct=direct) == 0
+        got = out.cpu().numpy()
+        if direct:
+            assert np.array_equal(got, ref), "max diff %g" % np.abs(got.astype(f32) - ref.astype(f32)).max()
+        else:
+            d = np.abs(got.astype(f32) - ref.astype(f32))
+            assert np.all(d <= F16_TOL * np.maximum(1.0, np.abs(ref.astype(f32)))), "max diff %g" % d.max()
+    # float32 tensors are refused (no silent conversion)
+    with pytest.raises(RuntimeError):
+        cabi.filterinterp_forward_ori_f16(gpu(torch, img.astype(f32)), gpu(torch, flow), gpu(torch, filt), out)
+
+
+def test_filterinterp_f16_views_and_alignment(torch_mod, cabi, oracle):
+    """odd row strides / odd offsets cannot be moved as dwords: those calls take the direct kernel."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    B, C, H, W = 1, 3, 20, 66
+    big = gpu16(torch, rng.random((B, C + 1, H + 2, W + 3), dtype=f32).astype(np.float16))
+    flow_np, filt_np = smooth_flow(rng, B, H, W, 3.0), (rng.random((B, 16, H, W), dtype=f32) * f32(0.25)).astype(f32)
+    for x0 in (0, 1, 2):
+        img = big[:, 1:, 1:H + 1, x0:x0 + W]
+        outbuf = torch.zeros_like(big)
+        out = outbuf[:, 1:, 1:H + 1, x0:x0 + W]
+        assert cabi.filterinterp_forward_ori_f16(img, gpu(torch, flow_np), gpu(torch, filt_np), out) == 0
+        ref = oracle.filterinterp_ori_fwd_f16(img.cpu().numpy(), flow_np, filt_np, fmad=1)
+        d = np.abs(out.cpu().numpy().astype(f32) - ref.astype(f32))
+        assert np.all(d <= F16_TOL * np.maximum(1.0, np.abs(ref.astype(f32))))
+        outbuf[:, 1:, 1:H + 1, x0:x0 + W] = 0
+        assert not outbuf.any()
+
+
 # ------------------------------------------------------------------ projections
 
 @pytest.mark.parametrize("B,H,W", [(1, 32, 48), (2, 17, 70), (1, 1, 1), (1, 40, 200)])
@@ -835,3 +902,25 @@ def test_other_baseline_sizes(torch_mod, cabi, oracle, raw):
         assert torch.equal(a, run_fi(torch, cabi, ctx, gf, gk, direct=True))
         ref = oracle.filterinterp_ori_fwd(ctx[:, [0, 63]].cpu().numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8)
         assert np.array_equal(cpu(a[:, [0, 63]]), ref)
+
+
+def test_full_size_1080p_f16_storage(torch_mod, cabi, oracle):
+    """cfg3 with fp16 storage: staged == direct to fp16 rounding on the whole 196-channel tensor,
+    the direct kernel == the oracle on sampled channels."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import synthetic as S
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    filt = S.filters(1, H, W, gen)
+    flow = S.flow(1, H, W, 8.0, gen, "smooth")
+    ctx = S.context(1, 196, H, W, gen).to(torch.float16)
+    gc, gf, gk = ctx.cuda(), flow.cuda(), filt.cuda()
+    a, b = torch.empty_like(gc), torch.empty_like(gc)
+    assert cabi.filterinterp_forward_ori_f16(gc, gf, gk, a) == 0
+    assert cabi.filterinterp_forward_ori_f16(gc, gf, gk, b, direct=True) == 0
+    d = (a.float() - b.float()).abs()
+    assert bool((d <= F16_TOL * torch.clamp(b.float().abs(), min=1.0)).all())
+    sel = [0, 97, 195]
+    ref = oracle.filterinterp_ori_fwd_f16(ctx[:, sel].numpy(), flow.numpy(), filt.numpy(), fmad=1, nthreads=8)
+    assert np.array_equal(b[:, sel].cpu().numpy(), ref)

@@ -67,6 +67,14 @@ def main():
                 ms = timed(lambda: cabi.filterinterp_forward_ori(frame, flow, filt, out3, direct=direct), args.iters * 5)
                 print("fi3   %-8s %-6s %8.4f ms %8.1f GB/s" % (model, tag, ms, 96.0 * px / ms / 1e6), flush=True)
 
+        if "fi196h" in ops:
+            ctx16, out16 = ctx.to(torch.float16), torch.empty_like(ctx, dtype=torch.float16)
+            for direct in (False, True):
+                ms = timed(lambda: cabi.filterinterp_forward_ori_f16(ctx16, flow, filt, out16, direct=direct), args.iters)
+                print("fi196 fp16 storage %-8s %-6s %8.4f ms %8.1f GB/s (856 B/px)"
+                      % (model, "direct" if direct else "lds", ms, 856.0 * px / ms / 1e6), flush=True)
+            del ctx16, out16
+
         def fp():
             cabi.flowprojection_forward(flow, count, proj, 1)
 

@@ -29,6 +29,7 @@ DEFOR_OFFSET, DEFOR_REGION, DEFOR_NOFILTER = 0, 1, 2
 SIGNATURES = {
     "vfi_filterinterp_forward_ori": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_backward_ori": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_forward_ori_f16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_forward_defor": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
                                        Strides, _p],
     "vfi_filterinterp_backward_defor": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides,
@@ -63,6 +64,7 @@ SIGNATURES = {
 # internal entry points used by the bench / tests to time one code path in isolation
 INTERNAL_SIGNATURES = {
     "vfi_filterinterp_forward_ori_direct": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_forward_ori_f16_direct": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
 }
 
 _lib = None
@@ -136,6 +138,19 @@ def filterinterp_forward_ori(input1, input2, input3, output, direct=False):
         fn = lib().vfi_filterinterp_forward_ori_direct if direct else lib().vfi_filterinterp_forward_ori
         return _finish(fn(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c, h, w, input3.size(1),
                           _st(input1), _st(input2), _st(input3), _stream(input1)))
+
+
+def filterinterp_forward_ori_f16(input1, input2, input3, output, direct=False):
+    """fp16 storage: input1 / output are float16 tensors, flow and filter float32."""
+    dims = _fi_checks(input1, input2, input3, output)
+    if dims is None or output.stride(3) != 1:
+        return 1
+    b, c, h, w = dims
+    _dev(input2), _dev(input3), _dev(output, torch.float16)
+    with torch.cuda.device(_dev(input1, torch.float16)):
+        fn = lib().vfi_filterinterp_forward_ori_f16_direct if direct else lib().vfi_filterinterp_forward_ori_f16
+        return _finish(fn(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c, h, w, input3.size(1),
+                          _st(input1), _st(input2), _st(input3), _stream(input2)))
 
 
 def filterinterp_backward_ori(input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3):

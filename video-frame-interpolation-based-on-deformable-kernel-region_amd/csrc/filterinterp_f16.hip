@@ -1,0 +1,381 @@
+// filterinterp_f16.hip -- FilterInterpolation (_ori forward) with fp16 STORAGE of the image and the
+// output and fp32 arithmetic (BASELINE.json configs[2]: "fp16 storage / fp32 accum").
+//
+// Semantics: filterinterpolation_cuda_kernel.cu:2692-2823 applied to the fp16 values widened to
+// fp32; flow and filter stay fp32; the fp32 result is rounded to fp16 (round to nearest even).
+//
+//   fi_forward_ori_direct_f16   one thread per pixel, any filter size, the reference's operation
+//                               order: bit-exact with the fp32 oracle run on the widened inputs and
+//                               rounded once.  Fallback of the staged kernel and its yardstick.
+//   fi_forward_ori_lds_f16      fs == 4, the 196-channel case: the tiling, LDS-DMA ring and channel
+//                               loop of fi_forward_ori_lds (filterinterp_lds.hip) with half the
+//                               bytes everywhere -- a staged window element is one dword = two
+//                               halves, a tap row is three dword LDS reads (instead of four) shifted
+//                               into place by v_alignbit with a per-lane amount, and the products
+//                               are v_fma_mix_f32 straight from the packed halves.
+// Two things differ from the fp32 staged kernel, both inside the stated fp16 tolerance (2e-3 for
+// images in [0, 1], tests/test_gpu_parity.py):
+//   * the pixel is one 16-term dot product with weights filter x bilinear weight folded once per
+//     tile (same products as the reference, one accumulation chain instead of four + blend);
+//   * image columns are never replicated in LDS (a dword holds two pixels, so per-pixel clamping
+//     of a dword load is impossible): a pixel whose taps leave the image left or right gets its
+//     window moved inside and the weights of the clamped taps added onto the column they clamp to.
+#include "filterinterp_dev.h"
+
+#include <hip/hip_fp16.h>
+#include <limits.h>
+
+namespace vfi {
+
+#define F16_TW 64
+#define F16_TH 16
+#define F16_PX 2
+#define F16_THREADS (F16_TW * F16_TH / F16_PX)
+#define F16_PASS_ROWS (F16_TH / F16_PX)
+#define F16_HDR 16
+#define F16_RING_DWORDS 15984
+#define F16_RMAX 5
+#define F16_KTOP 8
+
+typedef __attribute__((address_space(3))) void* f16_lptr_t;
+
+// fp32 -> fp16, round to nearest even, of a value that has first been rounded to fp32.  The empty asm
+// keeps hipcc from folding the conversion into the last FMA (v_fma_mixlo_f16 rounds the exact FMA
+// result to fp16 once; "the fp32 op, then .half()" rounds twice, and ties can fall the other way).
+__device__ __forceinline__ __half f16_store_value(float v) {
+    asm volatile("" : "+v"(v));
+    return __float2half_rn(v);
+}
+
+// ------------------------------------------------------------------ direct kernel (reference order)
+
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct_f16(
+    const __half* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    __half* __restrict__ out, int channel, int h, int w, int fs,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3) {
+    const int x = blockIdx.x * VFI_TX + threadIdx.x;
+    const int y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int b = blockIdx.z;
+    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+    const float fx = flow[0];
+    const float fy = flow[s2.c];
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    const __half* img = in1 + (int64_t)b * s1.b;
+    __half* dst = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    if (!fi_valid(fx, fy, x2, y2, w, h)) {
+        const __half* src = img + (int64_t)y * s1.h + x;
+        for (int c = 0; c < channel; ++c) dst[(int64_t)c * s1.c] = src[(int64_t)c * s1.c];
+        return;
+    }
+    const int ix = (int)x2, iy = (int)y2;
+    const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    const int R = L + fs, Bm = T + fs;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    for (int c = 0; c < channel; ++c) {
+        const __half* plane = img + (int64_t)c * s1.c;
+        float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        // quadrant by quadrant, rows outer / columns inner (:2749-2787)
+        for (int quad = 0; quad < 4; ++quad) {
+            const int j0 = (quad & 2) ? iy + 1 : T, j1 = (quad & 2) ? Bm : iy + 1;
+            const int i0 = (quad & 1) ? ix + 1 : L, i1 = (quad & 1) ? R : ix + 1;
+            float acc = 0.0f;
+            for (int j = j0; j < j1; ++j) {
+                const __half* row = plane + (int64_t)clampi(j, 0, h - 1) * s1.h;
+                for (int i = i0; i < i1; ++i)
+                    acc = fmaf(__half2float(row[clampi(i, 0, w - 1)]), fpx[(int64_t)((j - T) * fs + (i - L)) * s3.c], acc);
+            }
+            q[quad] = acc;
+        }
+        dst[(int64_t)c * s1.c] = f16_store_value(blend4(alpha, beta, q[0], q[1], q[2], q[3]));
+    }
+}
+
+// ------------------------------------------------------------------ LDS-staged kernel, fs == 4
+
+struct F16Window { int bx0, by0, bw, bh, pitch, h, w, hs; };   // bx0 even; bw, pitch in dwords
+struct F16Pixel {
+    bool valid, inimg;
+    int lbase;              // half index of the window origin inside a staged window (row pitch 2 * pitch)
+    unsigned pix;
+    float g[16];            // folded tap weights on the (possibly moved) 4x4 window
+};
+
+template <int K>
+__device__ __forceinline__ void f16_wait_windows(int younger_groups) {
+    switch (younger_groups) {
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K) : "memory"); break;
+    }
+}
+
+// the two halves of a packed dword, widened (v_fma_mix_f32 reads them in place)
+__device__ __forceinline__ float f16_lo(unsigned d) { return __half2float(__ushort_as_half((unsigned short)(d & 0xffffu))); }
+__device__ __forceinline__ float f16_hi(unsigned d) { return __half2float(__ushort_as_half((unsigned short)(d >> 16))); }
+
+template <int K>
+__device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img, __half* __restrict__ out, int64_t cs,
+                                                 int c_begin, int c_end, int tid, const F16Window& win,
+                                                 const F16Pixel (&px)[F16_PX], unsigned* __restrict__ ring, int R) {
+    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+    // dword e = tid + k*F16_THREADS of the staged window, row-major, `pitch` dwords per row; rows
+    // clamped to the image, columns never out of it; pad dwords get an out-of-range offset (the
+    // load returns 0 without touching memory)
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + k * F16_THREADS;
+        const int r = e / win.pitch;
+        const int col = e - r * win.pitch;
+        const unsigned off = 2u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + win.bx0 + 2 * col);
+        goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
+    }
+    const int plane_bytes = (2 * ((win.h - 1) * win.hs + win.w) + 3) & ~3;
+    constexpr int NP = K * F16_THREADS;                     // dwords per ring slot
+    const int D = R - 1;
+    auto issue = [&](int c, int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
+        unsigned* l = ring + slot * NP + tid;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (f16_lptr_t)(l + k * F16_THREADS), 4, goff[k], 0, 0, 0);
+    };
+    auto compute = [&](int c, int slot) {
+        __half* o = out + (int64_t)c * cs;
+        const unsigned* base = ring + slot * NP;
+#pragma unroll
+        for (int p = 0; p < F16_PX; ++p) {
+            if (px[p].valid) {
+                const unsigned* t = base + (px[p].lbase >> 1);
+                const unsigned sh = (unsigned)(px[p].lbase & 1) * 16u;
+                float acc = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned d0 = t[r * win.pitch], d1 = t[r * win.pitch + 1], d2 = t[r * win.pitch + 2];
+                    // ({d1,d0} >> sh) and ({d2,d1} >> sh): the four taps as two packed pairs
+                    const unsigned e0 = __builtin_amdgcn_alignbit(d1, d0, sh), e1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    acc = fmaf(f16_lo(e0), px[p].g[r * 4 + 0], acc);
+                    acc = fmaf(f16_hi(e0), px[p].g[r * 4 + 1], acc);
+                    acc = fmaf(f16_lo(e1), px[p].g[r * 4 + 2], acc);
+                    acc = fmaf(f16_hi(e1), px[p].g[r * 4 + 3], acc);
+                }
+                o[px[p].pix] = f16_store_value(acc);
+            }
+        }
+    };
+
+    if (c_begin >= c_end) return;
+    const int last = c_end - 1;
+    for (int j = 0; j < D; ++j)
+        if (c_begin + j <= last) issue(c_begin + j, j);
+    f16_wait_windows<K>(min(c_begin + D - 1, last) - c_begin);
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int c = c_begin; c <= last; ++c) {
+        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
+        compute(c, slot);
+        if (c < last) f16_wait_windows<K>(min(c + D, last) - (c + 1));
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int p = 0; p < F16_PX; ++p)
+        if (px[p].inimg && !px[p].valid)
+            for (int c = c_begin; c < c_end; ++c) out[(int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+}
+
+__global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
+    const __half* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    __half* __restrict__ out, int channel, int h, int w,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3,
+    int tiles_x, int tiles_y, int ntiles, int ch_per_group) {
+    __shared__ unsigned lds[F16_HDR + F16_RING_DWORDS];
+    int* box = reinterpret_cast<int*>(lds);
+
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int b = tile / (tiles_x * tiles_y);
+    const int trem = tile - b * (tiles_x * tiles_y);
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int c_begin = blockIdx.y * ch_per_group;
+    const int c_end = min(channel, c_begin + ch_per_group);
+
+    const int tid = threadIdx.x;
+    const int x = txi * F16_TW + (tid & (F16_TW - 1));
+    const int y0 = tyi * F16_TH + (tid >> 6);
+
+    F16Pixel px[F16_PX];
+    int L[F16_PX], Lc[F16_PX], T[F16_PX];
+    float alpha[F16_PX], beta[F16_PX];
+    int bx_lo = INT_MAX, by_lo = INT_MAX, bx_hi = INT_MIN, by_hi = INT_MIN;
+#pragma unroll
+    for (int p = 0; p < F16_PX; ++p) {
+        const int y = y0 + p * F16_PASS_ROWS;
+        px[p].inimg = x < w && y < h;
+        px[p].pix = (unsigned)(y * (int)s1.h + x);
+        float fx = 0.0f, fy = 0.0f;
+        if (px[p].inimg) {
+            const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+            fx = flow[0];
+            fy = flow[s2.c];
+        }
+        const float x2 = (float)x + fx;
+        const float y2 = (float)y + fy;
+        px[p].valid = px[p].inimg && fi_valid(fx, fy, x2, y2, w, h);
+        const int ix = px[p].valid ? (int)x2 : 1, iy = px[p].valid ? (int)y2 : 0;
+        L[p] = ix - 1;
+        T[p] = iy - 1;
+        Lc[p] = clampi(L[p], 0, w - 4);                     // the window moved inside the image (w >= 4)
+        alpha[p] = x2 - (float)ix;
+        beta[p] = y2 - (float)iy;
+        if (px[p].valid) {
+            bx_lo = min(bx_lo, Lc[p]); by_lo = min(by_lo, T[p]);
+            bx_hi = max(bx_hi, Lc[p] + 3); by_hi = max(by_hi, T[p] + 3);
+        }
+    }
+
+    if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
+    __syncthreads();
+    {
+        const int x0 = wave_min_i32(bx_lo), y0w = wave_min_i32(by_lo);
+        const int x1 = wave_max_i32(bx_hi), y1 = wave_max_i32(by_hi);
+        if ((tid & 63) == 0 && x0 != INT_MAX) {
+            atomicMin(&box[0], x0); atomicMin(&box[1], y0w);
+            atomicMax(&box[2], x1); atomicMax(&box[3], y1);
+        }
+    }
+    __syncthreads();
+    const bool any_valid = box[0] != INT_MAX;
+    const int bx0 = any_valid ? box[0] & ~1 : 0, by0 = box[1];          // even: dword-aligned rows
+    const int bw = any_valid ? (box[2] - bx0 + 2) >> 1 : 0;              // dwords per row
+    const int bh = any_valid ? box[3] - by0 + 1 : 0;
+    const int pitch = (bw + 31) & ~31;                                    // a multiple of the 32 banks
+    const int n = pitch * bh;
+
+    // ---- folded tap weights: filter tap x bilinear quadrant weight, clamped columns merged
+#pragma unroll
+    for (int p = 0; p < F16_PX; ++p) {
+        px[p].lbase = px[p].valid ? (T[p] - by0) * (2 * pitch) + (Lc[p] - bx0) : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) px[p].g[k] = 0.0f;
+        if (px[p].valid) {
+            const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)(y0 + p * F16_PASS_ROWS) * s3.h + x;
+            const float wx[2] = { 1.0f - alpha[p], alpha[p] }, wy[2] = { 1.0f - beta[p], beta[p] };
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float wgt = fpx[(int64_t)(r * 4 + k) * s3.c] * (wx[k >> 1] * wy[r >> 1]);
+                    const int kk = clampi(L[p] + k, 0, w - 1) - Lc[p];          // 0..3
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) px[p].g[r * 4 + q] += (kk == q) ? wgt : 0.0f;
+                }
+        }
+    }
+
+    const __half* img = in1 + (int64_t)b * s1.b;
+    __half* dst = out + (int64_t)b * s1.b;
+    const int kmax = (n + F16_THREADS - 1) / F16_THREADS;
+    if (kmax > F16_KTOP) {
+        // window too large for LDS: the same dot product gathered from global memory
+#pragma unroll
+        for (int p = 0; p < F16_PX; ++p) {
+            if (px[p].valid) {
+                for (int c = c_begin; c < c_end; ++c) {
+                    const __half* plane = img + (int64_t)c * s1.c;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const __half* row = plane + (int64_t)clampi(T[p] + r, 0, h - 1) * s1.h + Lc[p];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc = fmaf(__half2float(row[k]), px[p].g[r * 4 + k], acc);
+                    }
+                    dst[(int64_t)c * s1.c + px[p].pix] = f16_store_value(acc);
+                }
+            } else if (px[p].inimg) {
+                for (int c = c_begin; c < c_end; ++c) dst[(int64_t)c * s1.c + px[p].pix] = img[(int64_t)c * s1.c + px[p].pix];
+            }
+        }
+        return;
+    }
+
+    const F16Window win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
+    unsigned* ring = lds + F16_HDR;
+#define F16_RUN(K) f16_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
+                                       min(F16_RMAX, F16_RING_DWORDS / ((K) * F16_THREADS)))
+    if (kmax <= 2) F16_RUN(2);
+    else if (kmax == 3) F16_RUN(3);
+    else if (kmax == 4) F16_RUN(4);
+    else if (kmax <= 6) F16_RUN(6);
+    else F16_RUN(8);
+#undef F16_RUN
+}
+
+static int f16_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" int vfi_filterinterp_forward_ori_f16_direct(const void* input1, const float* input2, const float* input3,
+                                                        void* output, int batch, int channel, int h, int w,
+                                                        int filter_channels, vfi_strides s1, vfi_strides s2,
+                                                        vfi_strides s3, vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    const int fs = (int)sqrtf((float)filter_channels);
+    hipLaunchKernelGGL(fi_forward_ori_direct_f16, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       (const __half*)input1, input2, input3, (__half*)output, channel, h, w, fs, s1, s2, s3);
+    return launch_status();
+}
+
+extern "C" int vfi_filterinterp_forward_ori_f16(const void* input1, const float* input2, const float* input3,
+                                                 void* output, int batch, int channel, int h, int w,
+                                                 int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                                 vfi_stream_t stream) {
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
+    if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
+    // the staged kernel moves dwords: rows, planes and the base address must be 4-byte aligned
+    const bool staged = (int)sqrtf((float)filter_channels) == 4 && filter_channels == 16 && w >= 4 &&
+                        ((s1.h | s1.c | s1.b) & 1) == 0 && (reinterpret_cast<uintptr_t>(input1) & 3) == 0 &&
+                        (int64_t)h * s1.h * 2 < INT_MAX;
+    const int tiles_x = (w + F16_TW - 1) / F16_TW, tiles_y = (h + F16_TH - 1) / F16_TH;
+    const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
+    if (!staged || nt > (1 << 28))
+        return vfi_filterinterp_forward_ori_f16_direct(input1, input2, input3, output, batch, channel, h, w,
+                                                       filter_channels, s1, s2, s3, stream);
+    const int ntiles = (int)nt;
+    // split the channel range over blockIdx.y when that shortens the tail (as the fp32 kernel)
+    const int slots = f16_cu_count() * 2;
+    int best_groups = 1;
+    double best_cost = 0.0;
+    for (int g = 1; g <= 8 && g <= channel; g *= 2) {
+        const double wgs = (double)ntiles * g;
+        const double tail = ceil(wgs / slots) * slots / wgs;
+        const double bytes = (72.0 * g + 4.0 * channel) / (72.0 + 4.0 * channel);
+        const double cost = tail * bytes;
+        if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
+    }
+    const int ch_per_group = (channel + best_groups - 1) / best_groups;
+    const int groups = (channel + ch_per_group - 1) / ch_per_group;
+    hipLaunchKernelGGL(fi_forward_ori_lds_f16, dim3((unsigned)ntiles, (unsigned)groups, 1), dim3(F16_THREADS, 1, 1), 0,
+                       (hipStream_t)stream, (const __half*)input1, input2, input3, (__half*)output, channel, h, w, s1, s2,
+                       s3, tiles_x, tiles_y, ntiles, ch_per_group);
+    return launch_status();
+}
