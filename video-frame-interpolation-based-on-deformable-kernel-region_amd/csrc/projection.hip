@@ -22,15 +22,17 @@
 //                   its tile in LDS from the row segments on its list (one wave per
 //                   segment), then writes count and the normalised flow once,
 //                   coalesced.
-//   Z  proj_zero    only does work on the fallback path (zero-fills count / output).
-//   C  proj_average only does work on the fallback path.
-//   D  proj_fillhole
-// Launch order A, Z, B, C, D.  B writes every cell of count and output, so callers need not
-// zero-fill them (the reference's callers must: its splat accumulates into them).
+//   D  proj_finish  hole filling (and, on the fallback path, normalisation)
+// Launch order A, B, D.  B (or D on the fallback path) writes every cell of count and output,
+// so callers need not zero-fill them (the reference's callers must: its splat accumulates
+// into them).
 // Fallback: when any list overflows (fields with displacements of many tiles,
 // e.g. random flow of +-W/2), B instead splats its own source tile with global
-// atomics exactly like the reference, and C normalises.  The switch is a serial
-// number in the workspace written by A and read by B and C: no host round trip.
+// atomics exactly like the reference -- into three scratch planes of the workspace that
+// are zero between calls -- and D normalises them into count / output and fills holes from
+// them.  The switch is a serial number in the workspace written by A and read by B and D:
+// no host round trip, and no launch that exists only for the fallback.  (The scratch planes
+// are cleaned by the next call's A, whose workgroups see a "dirty" word.)
 //
 // Accumulation in B is 64-bit fixed point (ds_add_u64): on gfx950 an LDS float atomic add
 // costs ~170 cycles per wave instruction (measured, tools/probes/lds_atomic_probe.hip), an
@@ -66,6 +68,7 @@ namespace vfi {
 // (which depends on the frame size) cannot disturb the records.  A record's position depends on the tile index only, so calls with different frame
 // sizes can share the workspace without stale lengths.
 #define PROJ_WS_HDR 16
+#define PROJ_WS_DIRTY 1             // header word: the scratch planes of the fallback hold sums
 #define PROJ_WS_REC (4 + PROJ_LIST_CAP)
 #define PROJ_REC_VMAX 1
 #define PROJ_REC_CMAX 2
@@ -209,7 +212,14 @@ __device__ __forceinline__ int wmax(int v) { return wave_max_i32(v); }
 template <bool DEPTH, bool UP>
 __global__ __launch_bounds__(PROJ_THREADS, 8) void proj_bin(
     ProjFlow flow, const float* __restrict__ in2, ProjGeom g, vfi_strides s2,
-    int* __restrict__ ws, int* __restrict__ bits, int serial) {
+    int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats, int serial) {
+    if (ws[PROJ_WS_DIRTY] != 0) {
+        // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
+        // a slice per workgroup (D clears the word at the end of this call)
+        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
+        for (int64_t i = lo + threadIdx.x; i < hi; i += PROJ_THREADS) planes[i] = 0.0f;
+    }
     __shared__ int rect[PROJ_TH][4];                        // per row segment: tx0, ty0, tx1, ty1 (tx0 < 0: none)
     __shared__ int tmax[2];
     const int tile = blockIdx.x;
@@ -285,7 +295,7 @@ template <bool DEPTH, bool UP>
 __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     ProjFlow flow, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
     ProjGeom g, vfi_strides s1, vfi_strides s2, vfi_strides sc, int* __restrict__ ws, int* __restrict__ bits,
-    int serial) {
+    float* __restrict__ planes, int serial) {
     __shared__ unsigned long long acc[3][PROJ_TH][PROJ_TW];
     const int tile = blockIdx.x;
     const int b = tile / (g.tiles_x * g.tiles_y);
@@ -313,20 +323,21 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     if (tid < 3) rec[tid] = 0;                              // ... leave it empty for the next call
 
     if (fallback) {
-        // the reference's own scheme: this tile as SOURCE tile, global atomics into the planes Z zeroed
-        float* o0 = out + (int64_t)b * s1.b;
-        float* o1 = o0 + s1.c;
-        float* cn = count + (int64_t)b * sc.b;
+        // the reference's own scheme: this tile as SOURCE tile, global atomics into the dense scratch
+        // planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
+        const int64_t npx = (int64_t)(g.ntiles / (g.tiles_x * g.tiles_y)) * g.h * g.w;
+        float* o0 = planes + (int64_t)b * g.h * g.w;
+        float* o1 = o0 + npx;
+        float* cn = o1 + npx;
 #pragma unroll
         for (int r = 0; r < PROJ_TH / 4; ++r) {
             const ProjSplat s = proj_source<DEPTH, UP>(flow, in2, b, txi * PROJ_TW + lane, tyi * PROJ_TH + wave + r * 4,
                                                        g.h, g.w, s2);
             if (!s.valid) continue;
-            const int64_t oT = (int64_t)s.T * s1.h, oB = (int64_t)s.Bm * s1.h;
-            const int64_t cT = (int64_t)s.T * sc.h, cB = (int64_t)s.Bm * sc.h;
+            const int64_t oT = (int64_t)s.T * g.w, oB = (int64_t)s.Bm * g.w;
             atomicAdd(&o0[oT + s.L], s.ax); atomicAdd(&o0[oT + s.R], s.ax); atomicAdd(&o0[oB + s.L], s.ax); atomicAdd(&o0[oB + s.R], s.ax);
             atomicAdd(&o1[oT + s.L], s.ay); atomicAdd(&o1[oT + s.R], s.ay); atomicAdd(&o1[oB + s.L], s.ay); atomicAdd(&o1[oB + s.R], s.ay);
-            atomicAdd(&cn[cT + s.L], s.ac); atomicAdd(&cn[cT + s.R], s.ac); atomicAdd(&cn[cB + s.L], s.ac); atomicAdd(&cn[cB + s.R], s.ac);
+            atomicAdd(&cn[oT + s.L], s.ac); atomicAdd(&cn[oT + s.R], s.ac); atomicAdd(&cn[oB + s.L], s.ac); atomicAdd(&cn[oB + s.R], s.ac);
         }
         return;
     }
@@ -405,42 +416,6 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
     }
 }
 
-// Z: zero fill for the fallback path's atomics (otherwise 512 workgroups that return at once)
-__global__ __launch_bounds__(256) void proj_zero(
-    float* __restrict__ count, float* __restrict__ out, int batch, int h, int w, vfi_strides s1, vfi_strides sc,
-    const int* __restrict__ ws, int serial) {
-    if (ws[0] != serial) return;
-    const int64_t total = (int64_t)batch * h * w;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        const int b = (int)(i / ((int64_t)w * h));
-        count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = 0.0f;
-        float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-        o[0] = 0.0f;
-        o[s1.c] = 0.0f;
-    }
-}
-
-// C: pass 2 of the fallback path (otherwise 512 workgroups that return at once)
-__global__ __launch_bounds__(256) void proj_average(
-    const float* __restrict__ count, float* out, int batch, int h, int w, vfi_strides s1, vfi_strides sc,
-    const int* __restrict__ ws, int serial) {
-    if (ws[0] != serial) return;
-    const int64_t total = (int64_t)batch * h * w;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        const int b = (int)(i / ((int64_t)w * h));
-        const float c = count[(int64_t)b * sc.b + (int64_t)y * sc.h + x];
-        if (c > 0.0f) {
-            float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-            o[0] /= c;
-            o[s1.c] /= c;
-        }
-    }
-}
-
 // D: pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a non-hole
 // (never written by this pass) or is multiplied by 0.
 //
@@ -491,42 +466,77 @@ __device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn
     return r;
 }
 
-__global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_fillhole(
-    const float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
-    const int* __restrict__ ws, const int* __restrict__ bits, int serial) {
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_finish(
+    float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
+    int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole, int serial) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    if (x >= g.w || y >= g.h) return;
     const int b = blockIdx.z;
+    const bool fallback = ws[0] == serial;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && b == 0 && threadIdx.x == 0 && threadIdx.y == 0)
+        ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;               // read by the next call's A
+    if (x >= g.w || y >= g.h) return;
+    float* o0 = out + (int64_t)b * s1.b;
+    float* o1 = o0 + s1.c;
+    const int64_t row = (int64_t)y * s1.h;
+    if (fallback) {
+        // B left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
+        const int64_t npx = (int64_t)gridDim.z * g.h * g.w;
+        const float* p0 = planes + (int64_t)b * g.h * g.w;
+        const float* p1 = p0 + npx;
+        const float* pc = p1 + npx;
+        const int64_t me = (int64_t)y * g.w + x;
+        const float c = pc[me];
+        count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
+        if (c > 0.0f) {
+            o0[row + x] = p0[me] / c;
+            o1[row + x] = p1[me] / c;
+            return;
+        }
+        float v0 = 0.0f, v1 = 0.0f;
+        if (fillhole) {
+            const ProjScan l = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, -1), r = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, +1);
+            const ProjScan u = proj_walk_plain(pc, x, g.w, y, g.h, -1), d = proj_walk_plain(pc, x, g.w, y, g.h, +1);
+            if (l.cnt + r.cnt + u.cnt + d.cnt > 0.0f) {
+                const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f, rt = (r.cnt > 0.0f) ? 1.0f : 0.0f;
+                const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f, dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
+                const float den = lt + rt + ut + dt;
+                const int64_t il = (int64_t)y * g.w + l.pos, ir = (int64_t)y * g.w + r.pos;
+                const int64_t iu = (int64_t)u.pos * g.w + x, id = (int64_t)d.pos * g.w + x;
+                // a neighbour found by a walk has count > 0; the others carry weight 0 (their cell is a hole: value 0)
+                const float a0 = l.cnt > 0.0f ? p0[il] / l.cnt : 0.0f, b0 = r.cnt > 0.0f ? p0[ir] / r.cnt : 0.0f;
+                const float c0 = u.cnt > 0.0f ? p0[iu] / u.cnt : 0.0f, d0 = d.cnt > 0.0f ? p0[id] / d.cnt : 0.0f;
+                const float a1 = l.cnt > 0.0f ? p1[il] / l.cnt : 0.0f, b1 = r.cnt > 0.0f ? p1[ir] / r.cnt : 0.0f;
+                const float c1 = u.cnt > 0.0f ? p1[iu] / u.cnt : 0.0f, d1 = d.cnt > 0.0f ? p1[id] / d.cnt : 0.0f;
+                v0 = (lt * a0 + rt * b0 + ut * c0 + dt * d0) / den;
+                v1 = (lt * a1 + rt * b1 + ut * c1 + dt * d1) / den;
+            }
+        }
+        o0[row + x] = v0;
+        o1[row + x] = v1;
+        return;
+    }
+    if (!fillhole) return;
     const float* cn = count + (int64_t)b * sc.b;
     if (!(cn[(int64_t)y * sc.h + x] <= 0.0f)) return;
+    // B ran its normal path and left the bitmaps
+    const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
+    const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
+    const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
+    const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
+    // a walk that found nothing contributes weight 0; its position only has to be valid
     ProjScan l, r, u, d;
-    if (ws[0] != serial) {                                  // B ran its normal path and left the bitmaps
-        const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
-        const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
-        const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
-        const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
-        // a walk that found nothing contributes weight 0; its position only has to be valid
-        l.pos = xl < 0 ? x : xl; r.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
-        l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
-        r.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
-        u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
-        d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
-    } else {
-        l = proj_walk_plain(cn, (int64_t)y * sc.h, 1, x, g.w, -1);
-        r = proj_walk_plain(cn, (int64_t)y * sc.h, 1, x, g.w, +1);
-        u = proj_walk_plain(cn, x, sc.h, y, g.h, -1);
-        d = proj_walk_plain(cn, x, sc.h, y, g.h, +1);
-    }
+    l.pos = xl < 0 ? x : xl; r.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
+    l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
+    r.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
+    u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
+    d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
     if (l.cnt + r.cnt + u.cnt + d.cnt <= 0.0f) return;
     const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
     const float rt = (r.cnt > 0.0f) ? 1.0f : 0.0f;
     const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
     const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
     const float den = lt + rt + ut + dt;
-    float* o0 = out + (int64_t)b * s1.b;
-    float* o1 = o0 + s1.c;
-    const int64_t row = (int64_t)y * s1.h;
     o0[row + x] = (lt * o0[row + l.pos] + rt * o0[row + r.pos] + ut * o0[(int64_t)u.pos * s1.h + x] +
                    dt * o0[(int64_t)d.pos * s1.h + x]) / den;
     o1[row + x] = (lt * o1[row + l.pos] + rt * o1[row + r.pos] + ut * o1[(int64_t)u.pos * s1.h + x] +
@@ -586,11 +596,17 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_backward(
 // hipMalloc happens on the first call for a given stream / a larger frame only (do a warm-up call
 // before capturing into a graph); calls on one stream are ordered, so one workspace per stream is
 // enough and two streams never share one.
-struct ProjWorkspace { int device; hipStream_t stream; int* words; size_t capacity; int* bits; size_t bit_capacity; int serial; };
+struct ProjWorkspace {
+    int device; hipStream_t stream;
+    int* words; size_t capacity;
+    int* bits; size_t bit_capacity;
+    float* planes; size_t plane_capacity;       // fallback scratch: 3 dense planes, zero between calls
+    int serial;
+};
 static std::mutex g_ws_mutex;
 static std::vector<ProjWorkspace> g_ws;
 
-static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_words) {
+static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_words, size_t plane_floats) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_ws_mutex);
@@ -598,7 +614,7 @@ static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_wo
     for (auto& e : g_ws)
         if (e.device == dev && e.stream == st) w = &e;
     if (!w) {
-        g_ws.push_back(ProjWorkspace{dev, st, nullptr, 0, nullptr, 0, 0});
+        g_ws.push_back(ProjWorkspace{dev, st, nullptr, 0, nullptr, 0, nullptr, 0, 0});
         w = &g_ws.back();
     }
     if (w->capacity < words) {
@@ -609,6 +625,8 @@ static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_wo
         if (hipMemset(w->words, 0, words * sizeof(int)) != hipSuccess) return nullptr;
         w->capacity = words;
         w->serial = 0;
+        // the "dirty" word went with the old header: make the scratch planes clean by hand
+        if (w->planes && hipMemset(w->planes, 0, w->plane_capacity * sizeof(float)) != hipSuccess) return nullptr;
     }
     if (w->bit_capacity < bit_words) {
         if (w->bits) (void)hipFree(w->bits);
@@ -616,6 +634,14 @@ static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_wo
         w->bit_capacity = 0;
         if (hipMalloc(&w->bits, bit_words * sizeof(int)) != hipSuccess) return nullptr;
         w->bit_capacity = bit_words;                        // A clears what a call uses
+    }
+    if (w->plane_capacity < plane_floats) {
+        if (w->planes) (void)hipFree(w->planes);
+        w->planes = nullptr;
+        w->plane_capacity = 0;
+        if (hipMalloc(&w->planes, plane_floats * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemset(w->planes, 0, plane_floats * sizeof(float)) != hipSuccess) return nullptr;
+        w->plane_capacity = plane_floats;
     }
     w->serial += 1;                                         // serial 0 never matches: the header starts at 0
     return w;
@@ -640,23 +666,18 @@ static int project_forward(const ProjFlow& flow, const float* in2, float* count,
     if (bit_words > (size_t)INT_MAX) return VFI_ERR_SHAPE;
     g.rowmap = 0;
     g.colmap = batch * h * g.rmw;
-    ProjWorkspace* ws = proj_workspace(st, tile_words, bit_words);
+    ProjWorkspace* ws = proj_workspace(st, tile_words, bit_words, (size_t)3 * batch * h * w);
     if (!ws) return VFI_ERR_LAUNCH;
     hipLaunchKernelGGL((proj_bin<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, g, s2, ws->words,
-                       ws->bits, ws->serial);
-    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL(proj_zero, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
+                       ws->bits, ws->planes, (int64_t)ws->plane_capacity, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     hipLaunchKernelGGL((proj_gather<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, count, out, g, s1,
-                       s2, sc, ws->words, ws->bits, ws->serial);
+                       s2, sc, ws->words, ws->bits, ws->planes, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
-    hipLaunchKernelGGL(proj_average, dim3(512), dim3(256), 0, st, count, out, batch, h, w, s1, sc, ws->words, ws->serial);
+    // (also runs with fillhole == 0: it is where the fallback path normalises)
+    hipLaunchKernelGGL(proj_finish, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, st, count, out, g, s1, sc,
+                       ws->words, ws->bits, ws->planes, fillhole, ws->serial);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    if (fillhole) {
-        hipLaunchKernelGGL(proj_fillhole, grid, block, 0, st, count, out, g, s1, sc, ws->words, ws->bits, ws->serial);
-        if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    }
     return VFI_OK;
 }
 
