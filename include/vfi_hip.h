@@ -106,8 +106,8 @@ int vfi_filterinterp_backward_defor(int variant,
 /* ---- flowprojection_cuda -----------------------------------------------------
  * replaces FlowProjectionLayer_gpu_forward / _backward (flowprojection_cuda.cc:9-57, 59-114).
  * count [B,1,H,W] and output [B,2,H,W] are fully written (no zero fill needed).
- * The forward keeps a small per-stream device workspace (tile lists, bitmaps) that it
- * allocates on its first call for a stream and grows on demand: make one warm-up call
+ * The forward keeps a per-stream device workspace (tile lists, bitmaps, three scratch planes:
+ * about 13 bytes per pixel) that it allocates on its first call for a stream and grows on demand: make one warm-up call
  * before capturing calls into a HIP graph. */
 int vfi_flowprojection_forward(const float* input1, float* count, float* output,
                                int batch, int h, int w, int fillhole,
