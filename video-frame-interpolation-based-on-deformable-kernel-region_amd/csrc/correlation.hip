@@ -22,6 +22,7 @@
 namespace vfi {
 
 #define CORR_CC 8       // channels staged per LDS fill
+#define CORR_CC_ROWS 8   // ... in the small-frame kernel (16 measured the same: its chunk loop is LDS-bound, one workgroup per CU)
 
 __device__ __forceinline__ float padded_at(const float* __restrict__ f, int h, int w, int y, int x) {
     return (y >= 0 && y < h && x >= 0 && x < w) ? f[(int64_t)y * w + x] : 0.0f;
@@ -111,10 +112,10 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
     int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     constexpr int TW = 16, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;
-    constexpr int NT = 64 * D, NE = CORR_CC * LH * LW;      // threads, staged elements per chunk
+    constexpr int NT = 64 * D, NE = CORR_CC_ROWS * LH * LW;      // threads, staged elements per chunk
     constexpr int NPT = (NE + NT - 1) / NT;
-    __shared__ float tile[CORR_CC][LH][LW];
-    __shared__ float f1s[CORR_CC][TH * TW];
+    __shared__ float tile[CORR_CC_ROWS][LH][LW];
+    __shared__ float f1s[CORR_CC_ROWS][TH * TW];
 
     const int lane = threadIdx.x, tj = threadIdx.y;          // lane = pixel inside the tile
     const int tid = tj * 64 + lane;
@@ -147,16 +148,36 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
 #pragma unroll
     for (int ti = 0; ti < D; ++ti) acc[ti] = 0.0f;
 
-    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
-        const int cn = min(CORR_CC, channel - c0);
+    // The chunk loop is a dependent chain (global loads -> LDS -> products) and a small level has too
+    // few workgroups to hide it: the next chunk's values are fetched into registers before the
+    // current chunk is multiplied, and only written to LDS after it.
+    constexpr int NF1 = (CORR_CC_ROWS + D - 1) / D;          // channels of the first map each wave stages
+    float nv[NPT], nf1[NF1];
+    auto fetch = [&](int c0) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            nv[k] = (sok[k] && sch[k] < cn) ? f2[(int64_t)(c0 + sch[k]) * plane + soff[k]] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < NF1; ++q) {
+            const int cc = tj + q * D;
+            nf1[q] = (cc < cn && f1ok) ? f1[(int64_t)(c0 + cc) * plane + f1off] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC_ROWS) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const int e = tid + k * NT;
-            if (e < NE) (&tile[0][0][0])[e] = (sok[k] && sch[k] < cn) ? f2[(int64_t)(c0 + sch[k]) * plane + soff[k]] : 0.0f;
+            if (e < NE) (&tile[0][0][0])[e] = nv[k];
         }
-        if (tj < CORR_CC) f1s[tj][lane] = (tj < cn && f1ok) ? f1[(int64_t)(c0 + tj) * plane + f1off] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < NF1; ++q)
+            if (tj + q * D < CORR_CC_ROWS) f1s[tj + q * D][lane] = nf1[q];
         __syncthreads();
+        if (c0 + CORR_CC_ROWS < channel) fetch(c0 + CORR_CC_ROWS);
         for (int c = 0; c < cn; ++c) {
             const float av = f1s[c][lane];
 #pragma unroll
