@@ -86,6 +86,14 @@ def main():
         if "dproj" in ops:
             ms = timed(dfp, args.iters * 2)
             print("dproj %-8s        %8.4f ms %8.1f GB/s (all launches)" % (model, ms, 24.0 * px / ms / 1e6), flush=True)
+    for fthr in ([0, 64, 256, 1024] if "corrflat" in ops else []):
+        cabi.lib().vfi_debug_correlation_flat.argtypes = [__import__("ctypes").c_longlong]
+        cabi.lib().vfi_debug_correlation_flat(fthr)
+        for a, b in S.correlation_features(1, h, w, S.generator()):
+            a, b = a.to(dev), b.to(dev)
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            print("corr flat<%-5d C=%-3d %4dx%-4d %8.4f ms" % (fthr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
+        cabi.lib().vfi_debug_correlation_flat(64)
     for thr in ([256, 1 << 40, 0] if "corrknob" in ops else []):
         cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
         cabi.lib().vfi_debug_correlation(thr)

@@ -192,6 +192,42 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
     }
 }
 
+// k == 1, strides 1, tiny frames (the coarsest pyramid levels: a few hundred pixels, up to 196
+// channels): one thread per output element, x fastest, so a wave reads 64 consecutive pixels of each
+// map; eight channels in flight per thread.  A tiled kernel leaves most of the chip idle here (10
+// workgroups for 18x31).  Sequential channel order, as everywhere.
+template <int MD>
+__global__ __launch_bounds__(256) void corr_forward_k1_flat(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
+    int batch, int channel, int h, int w, int oh, int ow, int org) {
+    constexpr int D = 2 * MD + 1;
+    const int64_t total = (int64_t)batch * D * D * oh * ow;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int ox = (int)(gid % ow);
+    const int oy = (int)((gid / ow) % oh);
+    const int tc = (int)((gid / ((int64_t)ow * oh)) % (D * D));
+    const int b = (int)(gid / ((int64_t)ow * oh * D * D));
+    const int y1 = oy + org, x1 = ox + org;
+    const int y2 = y1 + tc / D - MD, x2 = x1 + tc % D - MD;
+    float acc = 0.0f;
+    if (y1 >= 0 && y1 < h && x1 >= 0 && x1 < w && y2 >= 0 && y2 < h && x2 >= 0 && x2 < w) {     // else zero padding
+        const int64_t plane = (int64_t)h * w;
+        const float* p1 = in1 + (int64_t)b * channel * plane + (int64_t)y1 * w + x1;
+        const float* p2 = in2 + (int64_t)b * channel * plane + (int64_t)y2 * w + x2;
+        int c = 0;
+        for (; c + 8 <= channel; c += 8) {
+            float a[8], v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k] = p1[(int64_t)(c + k) * plane]; v[k] = p2[(int64_t)(c + k) * plane]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = fmaf(a[k], v[k], acc);
+        }
+        for (; c < channel; ++c) acc = fmaf(p1[(int64_t)c * plane], p2[(int64_t)c * plane], acc);
+    }
+    out[gid] = acc / (float)channel;
+}
+
 // any kernel size / strides: one thread per output element, sequential channel order
 __global__ __launch_bounds__(256) void corr_forward_generic(
     const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
@@ -283,7 +319,10 @@ using namespace vfi;
 
 // development knob: number of 32x8 tiles from which the one-lane-per-pixel kernel is used
 static long long g_corr_big_threshold = 256;
+// ... and number of 16x4 tiles below which the one-thread-per-output kernel is used
+static long long g_corr_flat_threshold = 64;    // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
 extern "C" void vfi_debug_correlation(long long big_threshold) { g_corr_big_threshold = big_threshold; }
+extern "C" void vfi_debug_correlation_flat(long long flat_threshold) { g_corr_flat_threshold = flat_threshold; }
 
 extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
                                             int stride1, int stride2, int* out_channels, int* out_h, int* out_w) {
@@ -314,6 +353,10 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
             const dim3 grid((ow + 31) / 32, (oh + 7) / 8, batch);
             hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, input1, input2, output,
                                channel, h, w, oh, ow, max_displacement - pad_size);
+        } else if ((int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch < g_corr_flat_threshold) {
+            const int64_t total = (int64_t)batch * oc * oh * ow;
+            hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,
+                               input2, output, batch, channel, h, w, oh, ow, max_displacement - pad_size);
         } else {
             const dim3 grid((ow + 15) / 16, (oh + 3) / 4, batch);
             hipLaunchKernelGGL(corr_forward_k1_rows<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
