@@ -80,6 +80,38 @@ __global__ __launch_bounds__(512) void walk4(const float4* __restrict__ in, floa
     }
 }
 
+// float4 lanes on a 64-pixel-wide tile: 16 lanes per row (256-byte pieces), 4 rows per wave instruction
+template <int TH, int UNROLL>
+__global__ __launch_bounds__(512) void walk4n(const float4* __restrict__ in, float4* __restrict__ out, int C, int H, int W4,
+                                              int tiles_x) {
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    constexpr int PX = TH / 32;                             // 512 threads = 16 lanes x 32 rows per pass
+    const int x = tx * 16 + (threadIdx.x & 15);
+    const int r = threadIdx.x >> 4;
+    const size_t cs = (size_t)H * W4;
+    int off[PX];
+    bool ok[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int y = ty * TH + r + p * 32;
+        ok[p] = x < W4 && y < H;
+        off[p] = ok[p] ? y * W4 + x : 0;
+    }
+    for (int c = 0; c < C; c += UNROLL) {
+        float4 v[UNROLL][PX];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) v[u][p] = (c + u < C) ? in[(size_t)(c + u) * cs + off[p]] : float4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+                if (ok[p] && c + u < C) { float4 t = v[u][p]; t.x += 1.0f; out[(size_t)(c + u) * cs + off[p]] = t; }
+    }
+}
+
 template <typename F>
 static float timeit(F&& f) {
     hipEvent_t a, b;
@@ -136,6 +168,13 @@ int main() {
         printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u2, 2 workgroups per CU", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
         ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 4, 0, 16000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
         printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u4, 2 workgroups per CU", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        {
+            const int txn = (W4 + 15) / 16;
+            ms = timeit([&] { hipLaunchKernelGGL((walk4n<32, 1>), dim3(txn * ((H + 31) / 32)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txn); });
+            printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 64x32 tile (256-byte row pieces) u1", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+            ms = timeit([&] { hipLaunchKernelGGL((walk4n<64, 1>), dim3(txn * ((H + 63) / 64)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txn); });
+            printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 64x64 tile (256-byte row pieces) u1", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
+        }
         ms = timeit([&] { hipLaunchKernelGGL((walk4<8, 1, 0, 10000>), dim3(txs * ((H + 7) / 8)), dim3(512), 0, 0, (const float4*)in, (float4*)out, C, H, W4, txs); });
         printf("%-62s %7.3f ms %7.1f GB/s\n", "copy float4 256x8 u1, 4 workgroups per CU (32 waves, LDS 40K)", ms, 2.0 * n * 4 / 1e9 / ms * 1e3);
     }
