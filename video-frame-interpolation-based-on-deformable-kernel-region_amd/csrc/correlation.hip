@@ -70,9 +70,12 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
     const bool f1ok = y1 >= 0 && y1 < h && x1 >= 0 && x1 < w;
     const int f1off = f1ok ? y1 * w + x1 : 0;
 
-    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
+    // the next chunk's values are fetched into registers before the current chunk is multiplied and
+    // written to LDS after it: the finest level has ~2 workgroups per CU, too few to hide the
+    // load -> LDS -> multiply chain otherwise
+    float nv[CORR_CC][NI][NJ], na[CORR_CC];
+    auto fetch = [&](int c0) {
         const int cn = min(CORR_CC, channel - c0);
-        __syncthreads();
 #pragma unroll
         for (int c = 0; c < CORR_CC; ++c) {
             const float* p = f2 + (int64_t)(c0 + c) * plane;
@@ -80,14 +83,26 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (sin[i][j]) tile[c][ty + i * CORR_TH][tx + j * CORR_TW] = (cok && sok[i][j]) ? p[soff[i][j]] : 0.0f;
+                for (int j = 0; j < NJ; ++j) nv[c][i][j] = (cok && sok[i][j]) ? p[soff[i][j]] : 0.0f;
+            na[c] = (cok && f1ok) ? f1[(int64_t)(c0 + c) * plane + f1off] : 0.0f;
         }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC) {
+        const int cn = min(CORR_CC, channel - c0);
+        __syncthreads();
         float a[CORR_CC];
 #pragma unroll
-        for (int c = 0; c < CORR_CC; ++c)
-            a[c] = (c < cn && f1ok) ? f1[(int64_t)(c0 + c) * plane + f1off] : 0.0f;
+        for (int c = 0; c < CORR_CC; ++c) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (sin[i][j]) tile[c][ty + i * CORR_TH][tx + j * CORR_TW] = nv[c][i][j];
+            a[c] = na[c];
+        }
         __syncthreads();
+        if (c0 + CORR_CC < channel) fetch(c0 + CORR_CC);
         for (int c = 0; c < cn; ++c) {
             const float av = a[c];
 #pragma unroll
