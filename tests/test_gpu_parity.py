@@ -457,7 +457,12 @@ def test_separableconv_and_flow(torch_mod, cabi, oracle, fs):
 
 @pytest.mark.parametrize("C,H,W,pad,k,md,s1,s2", [(32, 20, 40, 4, 1, 4, 1, 1), (196, 9, 13, 4, 1, 4, 1, 1),
                                                    (7, 8, 33, 4, 1, 4, 1, 1), (5, 12, 14, 3, 3, 4, 1, 2),
-                                                   (8, 16, 18, 20, 1, 20, 2, 2), (3, 10, 10, 2, 1, 4, 1, 1)])
+                                                   (8, 16, 18, 20, 1, 20, 2, 2), (3, 10, 10, 2, 1, 4, 1, 1),
+                                                   # one shape per PWC-configuration kernel: two-pixel 16-byte-staged
+                                                   # (aligned rows, >= 64 tiles), one-pixel tiled (unaligned rows),
+                                                   # big tiles (unaligned, >= 256 of them); the small ones above are flat
+                                                   (6, 32, 128, 4, 1, 4, 1, 1), (19, 41, 256, 4, 1, 4, 1, 1),
+                                                   (5, 33, 130, 4, 1, 4, 1, 1), (3, 136, 514, 4, 1, 4, 1, 1)])
 def test_correlation_forward(torch_mod, cabi, oracle, C, H, W, pad, k, md, s1, s2):
     torch = torch_mod
     rng = np.random.default_rng(C + H)

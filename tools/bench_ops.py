@@ -94,6 +94,16 @@ def main():
             ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
             print("corr flat<%-5d C=%-3d %4dx%-4d %8.4f ms" % (fthr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
         cabi.lib().vfi_debug_correlation_flat(64)
+    for r2, thr in ([(1, 256), (1, 1 << 40), (0, 256), (0, 1 << 40)] if "corrrows2" in ops else []):
+        cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
+        cabi.lib().vfi_debug_correlation(thr)
+        cabi.lib().vfi_debug_correlation_rows2(r2)
+        for a, b in S.correlation_features(1, h, w, S.generator()):
+            a, b = a.to(dev), b.to(dev)
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            print("corr rows2=%d big>=%-14d C=%-3d %4dx%-4d %8.4f ms" % (r2, thr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
+        cabi.lib().vfi_debug_correlation(256)
+        cabi.lib().vfi_debug_correlation_rows2(1)
     for thr in ([256, 1 << 40, 0] if "corrknob" in ops else []):
         cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
         cabi.lib().vfi_debug_correlation(thr)

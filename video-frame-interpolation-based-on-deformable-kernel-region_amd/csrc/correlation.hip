@@ -207,6 +207,126 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
     }
 }
 
+// k == 1, strides 1, frames whose rows are 16-byte aligned: tile of 32x4 output pixels,
+// threadIdx.y = displacement row tj, a lane owns TWO horizontally adjacent pixels.  The window and the
+// first map are staged as 16-byte units (global_load_dwordx4 -> ds_write_b128: a quarter of the
+// vector-memory and LDS-write instructions of the one-float staging, which is what bounds the other
+// tiled kernels at one workgroup per CU); per channel a lane reads the 10 values its two 9-wide
+// displacement rows share as five aligned ds_read_b64 for 18 multiply-adds.  Same sequential
+// channel order.
+template <int MD>
+__global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
+    int channel, int h, int w, int oh, int ow, int org) {
+    constexpr int D = 2 * MD + 1;
+    constexpr int TW = 32, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;          // LW = 40: 10 aligned 16-byte units
+    constexpr int NT = 64 * D;
+    constexpr int UW = LW / 4, NU = CORR_CC_ROWS * LH * UW;                      // staged 16-byte units per chunk
+    constexpr int NPT = (NU + NT - 1) / NT;
+    constexpr int FU = CORR_CC_ROWS * TH * (TW / 4);                             // ... of the first map
+    constexpr int NF1 = (FU + NT - 1) / NT;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile[CORR_CC_ROWS][LH][LW];
+    __shared__ __attribute__((aligned(16))) float f1s[CORR_CC_ROWS][TH * TW];
+
+    const int lane = threadIdx.x, tj = threadIdx.y;
+    const int tid = tj * 64 + lane;
+    const int px = 2 * (lane & 15), py = lane >> 4;
+    const int ox = blockIdx.x * TW + px, oy = blockIdx.y * TH + py;
+    const int b = blockIdx.z;
+    const int64_t plane = (int64_t)h * w;
+    const float* f1 = in1 + (int64_t)b * channel * plane;
+    const float* f2 = in2 + (int64_t)b * channel * plane;
+    // window origin in input coordinates; a multiple of 4 columns (the host checks org and MD), so with
+    // w a multiple of 4 every 16-byte unit lies wholly inside or wholly outside the frame
+    const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;
+
+    // staging plans: unit e = tid + k*NT of the chunk's [CC][LH][UW] window block and of its
+    // [CC][TH][TW/4] first-map block (constant divisors)
+    int soff[NPT], sch[NPT];
+    bool sok[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (LH * UW), rem = e - c * (LH * UW);
+        const int r = rem / UW, col = 4 * (rem - r * UW);
+        const int gy = wy0 + r, gx = wx0 + col;
+        sch[k] = c;
+        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = sok[k] ? gy * w + gx : 0;
+    }
+    int foff[NF1], fch[NF1];
+    bool fok[NF1];
+#pragma unroll
+    for (int k = 0; k < NF1; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
+        const int gy = blockIdx.y * TH + rem / (TW / 4) + org, gx = blockIdx.x * TW + 4 * (rem % (TW / 4)) + org;
+        fch[k] = c;
+        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = fok[k] ? gy * w + gx : 0;
+    }
+
+    float acc[2][D];
+#pragma unroll
+    for (int ti = 0; ti < D; ++ti) { acc[0][ti] = 0.0f; acc[1][ti] = 0.0f; }
+
+    // the next chunk's units are fetched into registers before the current chunk is multiplied
+    v4f nv[NPT], nf[NF1];
+    const v4f zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    auto fetch = [&](int c0) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const v4f*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+#pragma unroll
+        for (int k = 0; k < NF1; ++k)
+            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const v4f*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC_ROWS) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < NU) reinterpret_cast<v4f*>(&tile[0][0][0])[e] = nv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int e = tid + k * NT;
+            if (e < FU) reinterpret_cast<v4f*>(&f1s[0][0])[e] = nf[k];
+        }
+        __syncthreads();
+        if (c0 + CORR_CC_ROWS < channel) fetch(c0 + CORR_CC_ROWS);
+        for (int c = 0; c < cn; ++c) {
+            const v2f a = *reinterpret_cast<const v2f*>(&f1s[c][py * TW + px]);
+            const v2f* row = reinterpret_cast<const v2f*>(&tile[c][py + tj][px]);
+            float t[D + 1];
+#pragma unroll
+            for (int k = 0; k < (D + 1) / 2; ++k) {
+                const v2f q = row[k];
+                t[2 * k] = q.x;
+                t[2 * k + 1] = q.y;
+            }
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti) {
+                acc[0][ti] = fmaf(a.x, t[ti], acc[0][ti]);
+                acc[1][ti] = fmaf(a.y, t[ti + 1], acc[1][ti]);
+            }
+        }
+    }
+    const float nelems = (float)channel;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (ox + q < ow && oy < oh) {
+            float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[q][ti] / nelems;
+        }
+}
+
 // k == 1, strides 1, tiny frames (the coarsest pyramid levels: a few hundred pixels, up to 196
 // channels): one thread per output element, x fastest, so a wave reads 64 consecutive pixels of each
 // map; eight channels in flight per thread.  A tiled kernel leaves most of the chip idle here (10
@@ -338,6 +458,8 @@ static long long g_corr_big_threshold = 256;
 static long long g_corr_flat_threshold = 64;    // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
 extern "C" void vfi_debug_correlation(long long big_threshold) { g_corr_big_threshold = big_threshold; }
 extern "C" void vfi_debug_correlation_flat(long long flat_threshold) { g_corr_flat_threshold = flat_threshold; }
+static int g_corr_rows2 = 1;        // two pixels per lane in the tiled kernel
+extern "C" void vfi_debug_correlation_rows2(int on) { g_corr_rows2 = on; }
 
 extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
                                             int stride1, int stride2, int* out_channels, int* out_h, int* out_w) {
@@ -364,14 +486,22 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
     const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
     if (kernel_size == 1 && stride1 == 1 && stride2 == 1 && max_displacement == 4) {
         const int64_t big_tiles = (int64_t)((ow + 31) / 32) * ((oh + 7) / 8) * batch;
-        if (big_tiles >= g_corr_big_threshold) {
-            const dim3 grid((ow + 31) / 32, (oh + 7) / 8, batch);
-            hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, input1, input2, output,
-                               channel, h, w, oh, ow, max_displacement - pad_size);
-        } else if ((int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch < g_corr_flat_threshold) {
+        const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
+        // 16-byte staging needs rows, planes and bases aligned (plane = h * w floats)
+        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
+                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 15) == 0;
+        if (small_tiles < g_corr_flat_threshold) {
             const int64_t total = (int64_t)batch * oc * oh * ow;
             hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,
                                input2, output, batch, channel, h, w, oh, ow, max_displacement - pad_size);
+        } else if (g_corr_rows2 && aligned) {
+            const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
+            hipLaunchKernelGGL(corr_forward_k1_rows2<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
+                               channel, h, w, oh, ow, max_displacement - pad_size);
+        } else if (big_tiles >= g_corr_big_threshold) {
+            const dim3 grid((ow + 31) / 32, (oh + 7) / 8, batch);
+            hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, input1, input2, output,
+                               channel, h, w, oh, ow, max_displacement - pad_size);
         } else {
             const dim3 grid((ow + 15) / 16, (oh + 3) / 4, batch);
             hipLaunchKernelGGL(corr_forward_k1_rows<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
