@@ -135,6 +135,28 @@ int vfi_depthflowprojection_backward(const float* input1, const float* input2,
                                      vfi_strides s1, vfi_strides s2, vfi_strides sc,
                                      vfi_stream_t stream);
 
+/* ---- mindepthflowprojection_cuda --------------------------------------------
+ * replaces minDepthFlowProjectionLayer_gpu_forward / _backward
+ * (mindepthflowprojection_cuda.cc:12-66, 68-139).  Each target keeps the (negated) flow of the
+ * source with the largest weight `input2` that lands on it (top-left integer neighbour only) and
+ * that weight in `count`.  The reference does this with an unguarded read-compare-write and is
+ * scheduling dependent; this library returns what those statements give when the sources are
+ * visited in raster order (largest weight above the incoming `count`, first source on ties).
+ * count and output must be zero-filled by the caller (untouched targets keep their values).
+ * The forward keeps a per-stream scratch plane of 8 bytes per pixel.  The backward gives
+ * gradinput1 only: the reference never writes gradinput2 (its code for it is commented out). */
+int vfi_mindepthflowprojection_forward(const float* input1, const float* input2,
+                                       float* count, float* output,
+                                       int batch, int h, int w, int fillhole,
+                                       vfi_strides s1, vfi_strides s2, vfi_strides sc,
+                                       vfi_stream_t stream);
+int vfi_mindepthflowprojection_backward(const float* input1, const float* input2,
+                                        const float* count, const float* gradoutput,
+                                        float* gradinput1,
+                                        int batch, int h, int w,
+                                        vfi_strides s1, vfi_strides s2, vfi_strides sc,
+                                        vfi_stream_t stream);
+
 /* ---- interpolation_cuda / interpolationch_cuda -------------------------------
  * replaces Interpolation[Ch]Layer_gpu_forward / _backward (interpolation_cuda.cc:10-60,
  * 63-121).  The C==3 restriction of `interpolation_cuda` lives in its shim. */

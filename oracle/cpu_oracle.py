@@ -7,6 +7,7 @@ dense float32 NCHW numpy arrays and mirrors one reference op:
   filterinterp_defor_fwd     filterinterpolation_cuda_kernel.cu:29-426, 1353-1496, 2070-2191
   flowproj_fwd/bwd           flowprojection_cuda_kernel.cu:29-301
   depthflowproj_fwd/bwd      depthflowprojection_cuda_kernel.cu:29-341
+  mindepthflowproj_fwd/bwd   mindepthflowprojection_cuda_kernel.cu:27-331 (sequential raster order)
   interp_fwd/bwd             interpolation_cuda_kernel.cu:29-202
   sepconv_fwd/bwd            separableconv_cuda_kernel.cu:29-135
   sepconvflow_fwd/bwd        separableconvflow_cuda_kernel.cu:29-173
@@ -151,6 +152,26 @@ def depthflowproj_bwd(flow, depth, count, out, gout):
     _check(lib().vfi_oracle_depthflowproj_bwd(_p(flow), _p(depth), _p(count), _p(out), _p(gout), _p(gflow),
                                               _p(gdepth), B, H, W), "depthflowproj_bwd")
     return gflow, gdepth
+
+
+def mindepthflowproj_fwd(flow, weight, fillhole=1, count0=None):
+    """count0: optional incoming `count` (the reference wrapper passes zeros); out starts at zero."""
+    flow, weight = _f32(flow), _f32(weight)
+    B, _, H, W = flow.shape
+    count = np.zeros((B, 1, H, W), np.float32) if count0 is None else _f32(count0).copy()
+    out = np.zeros_like(flow)
+    _check(lib().vfi_oracle_mindepthflowproj_fwd(_p(flow), _p(weight), _p(count), _p(out), B, H, W, int(fillhole)),
+           "mindepthflowproj_fwd")
+    return out, count
+
+
+def mindepthflowproj_bwd(flow, weight, count, gout):
+    flow, weight, count, gout = _f32(flow), _f32(weight), _f32(count), _f32(gout)
+    B, _, H, W = flow.shape
+    gflow = np.zeros_like(flow)
+    _check(lib().vfi_oracle_mindepthflowproj_bwd(_p(flow), _p(weight), _p(count), _p(gout), _p(gflow), B, H, W),
+           "mindepthflowproj_bwd")
+    return gflow
 
 
 def interp_fwd(img, flow, fmad=0):

@@ -253,6 +253,36 @@ def flowproj_fwd(flow, fillhole=1, depth=None):
     return out, count
 
 
+def mindepthflowproj_fwd(flow, weight, fillhole=1):
+    """Independent formulation of the defined MinDepthFlowProjection result: per target, the source with the
+    largest positive weight, lowest raster index on ties (np.lexsort instead of a sequential sweep).
+    Returns (out, count)."""
+    flow = flow.astype(f32)
+    B, _, H, W = flow.shape
+    valid, fx, fy, L, T, _, _ = _project_targets(flow, H, W)
+    wgt = weight[:, 0].astype(f32)
+    out = np.zeros((B, 2, H * W), f32)
+    count = np.zeros((B, 1, H * W), f32)
+    for b in range(B):
+        m = valid[b] & (wgt[b] > 0)
+        src = np.flatnonzero(m.ravel())
+        tgt = (T[b] * W + L[b]).ravel()[src]
+        wv = wgt[b].ravel()[src]
+        order = np.lexsort((src, -wv.astype(np.float64), tgt))      # by target, then weight descending, then index
+        tgt_s, src_s = tgt[order], src[order]
+        first = np.ones(len(order), bool)
+        first[1:] = tgt_s[1:] != tgt_s[:-1]
+        win_t, win_s = tgt_s[first], src_s[first]
+        out[b, 0, win_t] = -fx[b].ravel()[win_s]
+        out[b, 1, win_t] = -fy[b].ravel()[win_s]
+        count[b, 0, win_t] = wgt[b].ravel()[win_s]
+    out = out.reshape(B, 2, H, W)
+    count = count.reshape(B, 1, H, W)
+    if fillhole:
+        out = _fillhole(count, out)
+    return out, count
+
+
 def interp_fwd(img, flow):
     img, flow = img.astype(f32), flow.astype(f32)
     B, C, H, W = img.shape

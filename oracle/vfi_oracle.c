@@ -521,6 +521,88 @@ int vfi_oracle_depthflowproj_fwd(const float* flow, const float* depth, float* c
     return project(flow, depth, count, out, B, H, W, fillhole);
 }
 
+/* MinDepthFlowProjection: mindepthflowprojection_cuda_kernel.cu:27-119 executed sequentially in
+ * raster order of the source pixels (the reference's parallel read-compare-write is a race; the
+ * sequential order is the library's defined result), then the hole filling of :121-206. */
+int vfi_oracle_mindepthflowproj_fwd(const float* flow, const float* weight, float* count, float* out,
+                                    int B, int H, int W, int fillhole) {
+    if (B <= 0 || H <= 0 || W <= 0) return 1;
+    const i64 HW = (i64)H * W;
+    for (int b = 0; b < B; ++b) {
+        float* o0 = out + ((i64)b * 2 + 0) * HW;
+        float* o1 = out + ((i64)b * 2 + 1) * HW;
+        float* cn = count + (i64)b * HW;
+        for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const i64 px = (i64)y * W + x;
+            const float fx = flow[((i64)b * 2 + 0) * HW + px];
+            const float fy = flow[((i64)b * 2 + 1) * HW + px];
+            const float x2 = (float)x + fx;
+            const float y2 = (float)y + fy;
+            if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1))) continue;   /* (:68) */
+            const i64 t = (i64)(int)y2 * W + (int)x2;        /* top-left target only (:69-70, 76-84) */
+            const float wgt = weight[(i64)b * HW + px];
+            if (wgt > cn[t]) {
+                o0[t] = -fx;
+                o1[t] = -fy;
+                cn[t] = wgt;
+            }
+        }
+        if (!fillhole) continue;
+        /* holes read non-holes only, and only holes are written: any visiting order gives the same result */
+        for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (!(cn[(i64)y * W + x] <= 0.0f)) continue;
+            int lo = x; float lt = 0.0f;
+            while (lt == 0.0f && lo - 1 >= 0) { --lo; lt = cn[(i64)y * W + lo]; }
+            int ro = x; float rt = 0.0f;
+            while (rt == 0.0f && ro + 1 <= W - 1) { ++ro; rt = cn[(i64)y * W + ro]; }
+            int uo = y; float ut = 0.0f;
+            while (ut == 0.0f && uo - 1 >= 0) { --uo; ut = cn[(i64)uo * W + x]; }
+            int dn = y; float dt = 0.0f;
+            while (dt == 0.0f && dn + 1 <= H - 1) { ++dn; dt = cn[(i64)dn * W + x]; }
+            if (lt + rt + ut + dt <= 0.0f) continue;
+            lt = lt > 0.0f ? 1.0f : 0.0f;  rt = rt > 0.0f ? 1.0f : 0.0f;
+            ut = ut > 0.0f ? 1.0f : 0.0f;  dt = dt > 0.0f ? 1.0f : 0.0f;
+            float* po[2] = { o0, o1 };
+            for (int ch = 0; ch < 2; ++ch) {                 /* weights are 0/1: products exact, fmad irrelevant */
+                const float* p = po[ch];
+                const float acc = lt * p[(i64)y * W + lo] + rt * p[(i64)y * W + ro] + ut * p[(i64)uo * W + x] +
+                                  dt * p[(i64)dn * W + x];
+                po[ch][(i64)y * W + x] = acc / (lt + rt + ut + dt);
+            }
+        }
+    }
+    return 0;
+}
+
+/* mindepthflowprojection_cuda_kernel.cu:209-331: flow gradient only (the weight gradient is commented out there) */
+int vfi_oracle_mindepthflowproj_bwd(const float* flow, const float* weight, const float* count, const float* gout,
+                                    float* gflow, int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 1;
+    const i64 HW = (i64)H * W;
+    for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+        const i64 px = (i64)y * W + x;
+        const float fx = flow[((i64)b * 2 + 0) * HW + px];
+        const float fy = flow[((i64)b * 2 + 1) * HW + px];
+        const float x2 = (float)x + fx;
+        const float y2 = (float)y + fy;
+        if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1))) continue;
+        const int L = (int)x2, T = (int)y2;
+        const int R = mini(L + 1, W - 1), Bm = mini(T + 1, H - 1);
+        const float wgt = weight[(i64)b * HW + px];
+        const i64 t[4] = { (i64)T * W + L, (i64)T * W + R, (i64)Bm * W + L, (i64)Bm * W + R };
+        for (int k = 0; k < 4; ++k)                          /* (:271-286) */
+            if (wgt == count[(i64)b * HW + t[k]]) {
+                gflow[((i64)b * 2 + 0) * HW + px] += -gout[((i64)b * 2 + 0) * HW + t[k]];
+                gflow[((i64)b * 2 + 1) * HW + px] += -gout[((i64)b * 2 + 1) * HW + t[k]];
+            }
+    }
+    return 0;
+}
+
 int vfi_oracle_flowproj_bwd(const float* flow, const float* count, const float* gout,
                             float* gflow, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 1;

@@ -72,6 +72,13 @@ int vfi_oracle_depthflowproj_bwd(const float* flow, const float* depth, const fl
                                  const float* out, const float* gout, float* gflow, float* gdepth,
                                  int B, int H, int W);
 
+/* MinDepthFlowProjection mindepthflowprojection_cuda_kernel.cu:27-206 (sequential raster order) / 209-331;
+ * count/out/gflow must arrive zero-filled */
+int vfi_oracle_mindepthflowproj_fwd(const float* flow, const float* weight, float* count, float* out,
+                                    int B, int H, int W, int fillhole);
+int vfi_oracle_mindepthflowproj_bwd(const float* flow, const float* weight, const float* count, const float* gout,
+                                    float* gflow, int B, int H, int W);
+
 /* A5  interpolation_cuda_kernel.cu:29-98 / 102-202 (InterpolationCh identical) */
 int vfi_oracle_interp_fwd(const float* img, const float* flow, float* out,
                           int B, int C, int H, int W, int fmad);

@@ -128,6 +128,16 @@ def main():
     g["frame_y"] = (g["frame_padded"] * 1.3 - 0.1).astype(np.float32)           # values below 0 and above 1 too
     g["frame_back"] = o.padded_to_frame(g["frame_y"], 9, 14, 3, 4)
     np.savez_compressed(os.path.join(HERE, "glue.npz"), **g)
+    # MinDepthFlowProjection: defined result = sequential raster order; weights with ties
+    rng = np.random.default_rng(20250204)
+    g = {}
+    g["flow"] = (rng.normal(size=(2, 2, 19, 27)) * 2.5).astype(np.float32)
+    g["weight"] = (np.round(rng.uniform(0.1, 1.0, (2, 1, 19, 27)) * 8) / 8).astype(np.float32)
+    for fh in (0, 1):
+        g["out_fh%d" % fh], g["count_fh%d" % fh] = o.mindepthflowproj_fwd(g["flow"], g["weight"], fh)
+    g["gout"] = rng.normal(size=(2, 2, 19, 27)).astype(np.float32)
+    g["gflow"] = o.mindepthflowproj_bwd(g["flow"], g["weight"], g["count_fh0"], g["gout"])
+    np.savez_compressed(os.path.join(HERE, "mindepth.npz"), **g)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

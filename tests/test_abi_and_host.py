@@ -70,6 +70,7 @@ REFERENCE_EXPORTS = {
                                  "FilterInterpolationLayer_gpu_backward_nofilterwithdeforconv"],
     "flowprojection_cuda": ["FlowProjectionLayer_gpu_forward", "FlowProjectionLayer_gpu_backward"],
     "depthflowprojection_cuda": ["DepthFlowProjectionLayer_gpu_forward", "DepthFlowProjectionLayer_gpu_backward"],
+    "mindepthflowprojection_cuda": ["minDepthFlowProjectionLayer_gpu_forward", "minDepthFlowProjectionLayer_gpu_backward"],
     "interpolation_cuda": ["InterpolationLayer_gpu_forward", "InterpolationLayer_gpu_backward"],
     "interpolationch_cuda": ["InterpolationChLayer_gpu_forward", "InterpolationChLayer_gpu_backward"],
     "separableconv_cuda": ["SeparableConvLayer_gpu_forward", "SeparableConvLayer_gpu_backward"],

@@ -316,6 +316,66 @@ def test_depthflowprojection_forward(torch_mod, cabi, oracle, fillhole):
     assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref)
 
 
+@pytest.mark.parametrize("fillhole", [0, 1])
+def test_mindepthflowprojection(torch_mod, cabi, oracle, golden_dir, fillhole):
+    """Defined result = the reference statements in raster order (largest weight, first source on ties): bit-exact."""
+    torch = torch_mod
+    rng = np.random.default_rng(17)
+    cases = [(2, 33, 70, 3.0, 8), (1, 64, 200, 6.0, 2), (1, 1, 37, 1.0, 4), (1, 41, 1, 1.0, 4), (1, 130, 260, 0.4, 1000)]
+    for (B, H, W, sig, levels) in cases:
+        flow = smooth_flow(rng, B, H, W, sig) if min(H, W) >= 4 else (rng.standard_normal((B, 2, H, W)) * sig).astype(f32)
+        wgt = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * levels) / levels).astype(f32)   # few levels: many ties
+        count = torch.zeros((B, 1, H, W), device="cuda:0")
+        out = torch.zeros((B, 2, H, W), device="cuda:0")
+        assert cabi.mindepthflowprojection_forward(gpu(torch, flow), gpu(torch, wgt), count, out, fillhole) == 0
+        ref, rcount = oracle.mindepthflowproj_fwd(flow, wgt, fillhole)
+        assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref)
+        # backward on the forward's count
+        gout = rng.standard_normal((B, 2, H, W)).astype(f32)
+        g1 = torch.zeros((B, 2, H, W), device="cuda:0")
+        g2 = torch.zeros((B, 1, H, W), device="cuda:0")
+        assert cabi.mindepthflowprojection_backward(gpu(torch, flow), gpu(torch, wgt), count, out, gpu(torch, gout), g1, g2) == 0
+        assert np.array_equal(cpu(g1), oracle.mindepthflowproj_bwd(flow, wgt, rcount, gout)) and not cpu(g2).any()
+    # an incoming count is a floor; negative, zero and NaN weights never register
+    B, H, W = 1, 20, 30
+    flow = smooth_flow(rng, B, H, W, 2.0)
+    wgt = rng.uniform(-0.5, 1.0, (B, 1, H, W)).astype(f32)
+    wgt[0, 0, 3, 4] = np.nan
+    wgt[0, 0, 5, 6] = 0.0
+    count0 = rng.uniform(0.0, 0.6, (B, 1, H, W)).astype(f32)
+    count = gpu(torch, count0)
+    out = torch.zeros((B, 2, H, W), device="cuda:0")
+    assert cabi.mindepthflowprojection_forward(gpu(torch, flow), gpu(torch, wgt), count, out, fillhole) == 0
+    ref, rcount = oracle.mindepthflowproj_fwd(flow, wgt, fillhole, count0=count0)
+    assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref)
+    # committed fixture
+    g = np.load(os.path.join(golden_dir, "mindepth.npz"))
+    count = torch.zeros((2, 1, 19, 27), device="cuda:0")
+    out = torch.zeros((2, 2, 19, 27), device="cuda:0")
+    assert cabi.mindepthflowprojection_forward(gpu(torch, g["flow"]), gpu(torch, g["weight"]), count, out, fillhole) == 0
+    assert np.array_equal(cpu(out), g["out_fh%d" % fillhole]) and np.array_equal(cpu(count), g["count_fh%d" % fillhole])
+
+
+def test_mindepth_wrapper_mirror(torch_mod, cabi, oracle):
+    torch = torch_mod
+    from vfidkr_amd.my_package.MinDepthFlowProjection import minDepthFlowProjectionModule
+    rng = np.random.default_rng(19)
+    B, H, W = 2, 24, 40
+    flow_np = smooth_flow(rng, B, H, W, 2.0)
+    wgt_np = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    for rg in (False, True):
+        o = minDepthFlowProjectionModule(rg)(gpu(torch, flow_np), gpu(torch, wgt_np))
+        assert np.array_equal(cpu(o), oracle.mindepthflowproj_fwd(flow_np, wgt_np, 0 if rg else 1)[0])
+    fl = gpu(torch, flow_np).requires_grad_(True)
+    wg = gpu(torch, wgt_np).requires_grad_(True)
+    o = minDepthFlowProjectionModule(True)(fl, wg)
+    gout = rng.standard_normal((B, 2, H, W)).astype(f32)
+    o.backward(gpu(torch, gout))
+    _, rcount = oracle.mindepthflowproj_fwd(flow_np, wgt_np, 0)
+    assert np.array_equal(cpu(fl.grad), oracle.mindepthflowproj_bwd(flow_np, wgt_np, rcount, gout))
+    assert not cpu(wg.grad).any()
+
+
 def test_projection_edge_cases(torch_mod, cabi, oracle):
     torch = torch_mod
     H, W = 12, 70

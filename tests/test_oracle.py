@@ -191,6 +191,45 @@ def test_case7_depth_collision(oracle):
     assert np.isclose(out[0, 0, 2, 3], -(d1 * 1.0 + d2 * -1.0) / (d1 + d2))
 
 
+def test_mindepth_c_equals_numpy_and_analytic(oracle, np_oracle):
+    rng = np.random.default_rng(11)
+    for (B, H, W, sig) in ((2, 13, 17, 2.0), (1, 24, 40, 4.0), (1, 8, 8, 0.3), (1, 1, 9, 1.0), (1, 7, 1, 1.0)):
+        flow = (rng.standard_normal((B, 2, H, W)) * sig).astype(f32)
+        wgt = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 4) / 4).astype(f32)      # many ties
+        for fh in (0, 1):
+            a, ca = oracle.mindepthflowproj_fwd(flow, wgt, fh)
+            b, cb = np_oracle.mindepthflowproj_fwd(flow, wgt, fh)
+            assert np.array_equal(ca, cb) and np.array_equal(a, b)
+    # two sources on one target: the nearer one (larger inverse depth) wins, whatever the order
+    H, W = 6, 8
+    flow = np.full((1, 2, H, W), 100.0, f32)                 # everything else leaves the frame
+    wgt = np.ones((1, 1, H, W), f32)
+    flow[0, :, 2, 1] = (2.25, 1.5)                           # (1,2) -> (3.25, 3.5) -> target (3,3)
+    flow[0, :, 4, 5] = (-1.5, -0.25)                         # (5,4) -> (3.5, 3.75) -> target (3,3)
+    for (w0, w1, winner) in ((0.5, 0.75, 1), (0.75, 0.5, 0), (0.5, 0.5, 0)):   # tie: first source in raster order
+        wgt[0, 0, 2, 1], wgt[0, 0, 4, 5] = w0, w1
+        out, count = oracle.mindepthflowproj_fwd(flow, wgt, 0)
+        assert count[0, 0, 3, 3] == max(w0, w1) and (count != 0).sum() == 1
+        exp = (-2.25, -1.5) if winner == 0 else (1.5, 0.25)
+        assert tuple(out[0, :, 3, 3]) == exp
+        filled, _ = oracle.mindepthflowproj_fwd(flow, wgt, 1)
+        # holes on row 3 and column 3 copy the only value found; the rest of the frame finds nothing and stays 0
+        assert np.all(filled[0, 0, 3, :] == exp[0]) and np.all(filled[0, 1, :, 3] == exp[1])
+        assert filled[0, 0, 0, 0] == 0
+    # an incoming count above every weight keeps the zeros; non-positive weights never register
+    out, count = oracle.mindepthflowproj_fwd(flow, wgt, 0, count0=np.full((1, 1, H, W), 2.0, f32))
+    assert not out.any() and np.all(count == 2.0)
+    out, count = oracle.mindepthflowproj_fwd(flow, -wgt, 0)
+    assert not out.any() and not count.any()
+    # backward: a source receives -gout of each of its four neighbours whose count equals its weight
+    wgt[0, 0, 2, 1], wgt[0, 0, 4, 5] = 0.5, 0.75
+    _, count = oracle.mindepthflowproj_fwd(flow, wgt, 0)
+    gout = rng.standard_normal((1, 2, H, W)).astype(f32)
+    g = oracle.mindepthflowproj_bwd(flow, wgt, count, gout)
+    assert np.array_equal(g[0, :, 4, 5], -gout[0, :, 3, 3]) and not g[0, :, 2, 1].any()
+    assert (g != 0).sum() == 2
+
+
 def test_case8_correlation_constant(oracle):
     f = np.ones((1, 1, 10, 12), f32)
     out = oracle.correlation_fwd(f, f, 4, 1, 4, 1, 1)
@@ -504,6 +543,12 @@ def test_golden_fixtures_reproduced(oracle, golden_dir):
         assert np.array_equal(out, g["out_fh%d" % fh]) and np.array_equal(count, g["count_fh%d" % fh])
         out, count = oracle.depthflowproj_fwd(g["flow"], g["depth"], fh)
         assert np.array_equal(out, g["dout_fh%d" % fh]) and np.array_equal(count, g["dcount_fh%d" % fh])
+
+    g = np.load(os.path.join(golden_dir, "mindepth.npz"))
+    for fh in (0, 1):
+        out, count = oracle.mindepthflowproj_fwd(g["flow"], g["weight"], fh)
+        assert np.array_equal(out, g["out_fh%d" % fh]) and np.array_equal(count, g["count_fh%d" % fh])
+    assert np.array_equal(oracle.mindepthflowproj_bwd(g["flow"], g["weight"], g["count_fh0"], g["gout"]), g["gflow"])
 
     g = np.load(os.path.join(golden_dir, "warp_sepconv.npz"))
     assert np.array_equal(oracle.interp_fwd(g["img"], g["flow"]), g["out"])

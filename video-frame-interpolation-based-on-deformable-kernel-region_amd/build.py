@@ -2,7 +2,7 @@
 
   lib/libvfi_hip.so                hand-written HIP kernels + the C ABI of include/vfi_hip.h
                                    (hipcc --offload-arch=gfx950, csrc/Makefile)
-  ext/<module>.cpython-*.so        the reference's eight pybind11 module names on top of the
+  ext/<module>.cpython-*.so        the reference's nine pybind11 module names on top of the
                                    C ABI (csrc/shim/vfi_torch_shim.cpp, plain g++ against the
                                    torch headers; no kernels, no hipify)
 
@@ -22,7 +22,8 @@ EXT_DIR = os.path.join(PKG_DIR, "ext")
 LIB_PATH = os.path.join(LIB_DIR, "libvfi_hip.so")
 
 SHIM_MODULES = (
-    "filterinterpolation_cuda", "flowprojection_cuda", "depthflowprojection_cuda", "interpolation_cuda",
+    "filterinterpolation_cuda", "flowprojection_cuda", "depthflowprojection_cuda", "mindepthflowprojection_cuda",
+    "interpolation_cuda",
     "interpolationch_cuda", "separableconv_cuda", "separableconvflow_cuda", "correlation_cuda",
 )
 

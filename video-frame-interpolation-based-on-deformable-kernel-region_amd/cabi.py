@@ -38,6 +38,8 @@ SIGNATURES = {
     "vfi_flowprojection_backward": [_p, _p, _p, _p, _i, _i, _i, Strides, Strides, _p],
     "vfi_depthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_depthflowprojection_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_mindepthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_mindepthflowprojection_backward": [_p, _p, _p, _p, _p, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_interpolation_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
     "vfi_interpolation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
     "vfi_separableconv_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, Strides, _p],
@@ -261,6 +263,32 @@ def depthflowprojection_backward(input1, input2, count, output, gradoutput, grad
         return _finish(lib().vfi_depthflowprojection_backward(
             _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), _ptr(gradoutput), _ptr(gradinput1),
             _ptr(gradinput2), b, h, w, _st(input1), _st(input2), _st(count), _stream(input1)))
+
+
+def mindepthflowprojection_forward(input1, input2, count, output, fillhole):
+    """mindepthflowprojection_cuda.cc:12-66; count and output zero-filled by the caller."""
+    if input1.size(1) != 2 or input2.size(1) != 1:
+        return 1
+    if input1.stride(0) != output.stride(0) or input1.stride(1) != output.stride(1):
+        return 1
+    b, _, h, w = input1.shape
+    with torch.cuda.device(_dev(input1)):
+        return _finish(lib().vfi_mindepthflowprojection_forward(
+            _ptr(input1), _ptr(input2), _ptr(count), _ptr(output), b, h, w, int(fillhole), _st(input1), _st(input2),
+            _st(count), _stream(input1)))
+
+
+def mindepthflowprojection_backward(input1, input2, count, output, gradoutput, gradinput1, gradinput2):
+    """mindepthflowprojection_cuda.cc:68-139; `output` and `gradinput2` are accepted and unused, as in the reference."""
+    b, _, h, w = input1.shape
+    if input1.size(1) != 2 or input2.size(1) != 1 or tuple(count.shape) != (b, 1, h, w):
+        return 1
+    if input1.stride(0) != gradinput1.stride(0) or input1.stride(1) != gradinput1.stride(1):
+        return 1
+    with torch.cuda.device(_dev(input1)):
+        return _finish(lib().vfi_mindepthflowprojection_backward(
+            _ptr(input1), _ptr(input2), _ptr(count), _ptr(gradoutput), _ptr(gradinput1), b, h, w, _st(input1),
+            _st(input2), _st(count), _stream(input1)))
 
 
 # ---------------------------------------------------------------- interpolation_cuda / interpolationch_cuda

@@ -271,6 +271,44 @@ int DepthFlowProjectionLayer_gpu_backward(at::Tensor& input1, at::Tensor& input2
                                                    st(input1), st(input2), st(count), s.stream));
 }
 
+// ---------------------------------------------------------------- mindepthflowprojection_cuda
+
+// mindepthflowprojection_cuda.cc:12-66
+int minDepthFlowProjectionLayer_gpu_forward(at::Tensor& input1, at::Tensor& input2, at::Tensor& count,
+                                            at::Tensor& output, int fillhole) {
+    const int error = 1;
+    if (input1.size(1) != 2) return error;
+    const int batch = input1.size(0), h = input1.size(2), w = input1.size(3);
+    if (input2.size(1) != 1) return error;
+    if (input1.stride(0) != output.stride(0)) return error;
+    if (input1.stride(1) != output.stride(1)) return error;
+    StreamScope s(input1);
+    return finish(vfi_mindepthflowprojection_forward(cptr(input1), cptr(input2), mptr(count), mptr(output), batch, h, w,
+                                                     fillhole, st(input1), st(input2), st(count), s.stream));
+}
+
+// mindepthflowprojection_cuda.cc:68-139 (output and gradinput2 are passed and never used by the reference kernel)
+int minDepthFlowProjectionLayer_gpu_backward(at::Tensor& input1, at::Tensor& input2, at::Tensor& count,
+                                             at::Tensor& output, at::Tensor& gradoutput, at::Tensor& gradinput1,
+                                             at::Tensor& gradinput2) {
+    const int error = 1;
+    if (input1.size(1) != 2) return error;
+    const int batch = input1.size(0);
+    if (count.size(0) != batch) return error;
+    if (count.size(1) != 1) return error;
+    const int h = input1.size(2), w = input1.size(3);
+    if (input2.size(1) != 1) return error;
+    if (count.size(2) != h) return error;
+    if (count.size(3) != w) return error;
+    if (input1.stride(0) != gradinput1.stride(0)) return error;
+    if (input1.stride(1) != gradinput1.stride(1)) return error;
+    (void)output; (void)gradinput2;
+    StreamScope s(input1);
+    return finish(vfi_mindepthflowprojection_backward(cptr(input1), cptr(input2), cptr(count), cptr(gradoutput),
+                                                      mptr(gradinput1), batch, h, w, st(input1), st(input2), st(count),
+                                                      s.stream));
+}
+
 // ---------------------------------------------------------------- interpolation_cuda / interpolationch_cuda
 
 // interpolation_cuda.cc:10-60 ; interpolationch_cuda.cc drops the channel==3 test (:19)
@@ -478,6 +516,10 @@ PYBIND11_MODULE(flowprojection_cuda, m) {
 PYBIND11_MODULE(depthflowprojection_cuda, m) {
     m.def("DepthFlowProjectionLayer_gpu_forward", &DepthFlowProjectionLayer_gpu_forward, "DepthFlowProjection forward (HIP, gfx950)");
     m.def("DepthFlowProjectionLayer_gpu_backward", &DepthFlowProjectionLayer_gpu_backward, "DepthFlowProjection backward (HIP, gfx950)");
+}
+PYBIND11_MODULE(mindepthflowprojection_cuda, m) {
+    m.def("minDepthFlowProjectionLayer_gpu_forward", &minDepthFlowProjectionLayer_gpu_forward, "minDepthFlowProjection forward (HIP, gfx950)");
+    m.def("minDepthFlowProjectionLayer_gpu_backward", &minDepthFlowProjectionLayer_gpu_backward, "minDepthFlowProjection backward (HIP, gfx950)");
 }
 PYBIND11_MODULE(interpolation_cuda, m) {
     m.def("InterpolationLayer_gpu_forward", &InterpolationLayer_gpu_forward, "Interpolation forward (HIP, gfx950)");
