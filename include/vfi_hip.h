@@ -272,7 +272,12 @@ int vfi_pwc_warp_forward(const float* x, const float* flow, float* output,
  * u8 -> planar: dst[b,c,y,x] = src[b, clamp(y - pad_top), clamp(x - pad_left), c] / 255 for the padded
  * frame (h + pad_top + pad_bottom) x (w + pad_left + pad_right); src is dense [B,h,w,3] uint8.
  * planar -> u8: dst[b,y,x,c] = uint8(rint(255 * clip(src[b,c,top+y,left+x], 0, 1))), dst dense [B,h,w,3].
- * error sums: sums[0] += sum|a-b|, sums[1] += sum (a-b)^2 over n bytes (exact; caller zeroes sums). */
+ * error sums: sums[0] += sum|a-b|, sums[1] += sum (a-b)^2 over n bytes (exact; caller zeroes sums).
+ * ssim sums: sums[0] += sum of the SSIM map of every colour plane of every frame pair as the demo computes it
+ *   (demo_MiddleBury.py:40-162, 382-388: planes / 255, 11-tap sigma-1.5 Gaussian along H then W without padding,
+ *   data_range 1, K = (0.01, 0.03)), each value as a 2^-32 fixed-point integer (order-free; caller zeroes sums).
+ *   mean SSIM = sums[0] / 2^32 / (batch * 3 * (h - 10) * (w - 10)); a dimension below 11 is not smoothed and
+ *   contributes its full length instead of (length - 10), as in the reference.  a, b: dense [B,h,w,3] uint8. */
 int vfi_frame_u8_to_planar(const unsigned char* src_hwc, float* dst,
                            int batch, int h, int w, int pad_left, int pad_right, int pad_top, int pad_bottom,
                            vfi_strides sd, vfi_stream_t stream);
@@ -281,6 +286,8 @@ int vfi_planar_to_frame_u8(const float* src, unsigned char* dst_hwc,
                            vfi_strides ss, vfi_stream_t stream);
 int vfi_frame_error_sums(const unsigned char* a, const unsigned char* b, int64_t n,
                          unsigned long long* sums, vfi_stream_t stream);
+int vfi_frame_ssim_sums(const unsigned char* a, const unsigned char* b, int batch, int h, int w,
+                        long long* sums, vfi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -307,6 +307,34 @@ def frame_error(rec_u8, gt_u8):
     return err, (float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse)))
 
 
+def frame_ssim(rec_u8, gt_u8):
+    """demo_MiddleBury.py:382-388 -> ssim() :40-162 with its defaults: every colour plane / 255 is a single-channel
+    image; 11-tap Gaussian (sigma 1.5) along H then W, no padding (a dimension below 11 is not smoothed, :112-119);
+    data_range 1, K = (0.01, 0.03); mean of the SSIM map.  float64 throughout (the reference runs it in float32).
+    rec_u8, gt_u8: [B,h,w,3] uint8."""
+    x = np.moveaxis(rec_u8.astype(np.float32) / np.float32(255), 3, 1).astype(np.float64)      # ToTensor
+    y = np.moveaxis(gt_u8.astype(np.float32) / np.float32(255), 3, 1).astype(np.float64)
+    coords = np.arange(11, dtype=np.float64) - 11 // 2
+    g = np.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+
+    def blur(t):
+        for axis in (2, 3):
+            n = t.shape[axis]
+            if n < 11:
+                continue
+            t = sum(g[k] * np.take(t, np.arange(k, n - 10 + k), axis=axis) for k in range(11))
+        return t
+
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    mu1, mu2 = blur(x), blur(y)
+    s1 = blur(x * x) - mu1 * mu1
+    s2 = blur(y * y) - mu2 * mu2
+    s12 = blur(x * y) - mu1 * mu2
+    cs = (2 * s12 + C2) / (s1 + s2 + C2)
+    return float((((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs).mean())
+
+
 def filterinterp_ori_fwd_f16(img16, flow, filt, fmad=1, nthreads=1):
     """fp16 storage, fp32 arithmetic: the fp32 op on the widened image, rounded to half once."""
     assert img16.dtype == np.float16

@@ -681,6 +681,31 @@ def test_frame_boundary(torch_mod, cabi, oracle):
     assert fused.interpolation_error_and_psnr(fused.padded_to_frames(x, 40, 72, padding), frames) == (0.0, float("inf"))
 
 
+def test_frame_ssim(torch_mod, cabi, oracle):
+    """SSIM as demo_MiddleBury.py:382-388 reports it; float32 on the GPU against the float64 oracle."""
+    torch = torch_mod
+    from vfidkr_amd import fused
+    rng = np.random.default_rng(29)
+    for (B, h, w, noise) in ((1, 24, 31, 12), (2, 50, 97, 40), (1, 11, 11, 5), (1, 9, 30, 12), (1, 16, 7, 12),
+                             (1, 3, 5, 12), (1, 270, 480, 6)):
+        gt = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        if h >= 64:                                          # a smooth frame: flat regions stress the variance terms
+            yy, xx = np.mgrid[0:h, 0:w]
+            gt = np.stack([(127 + 100 * np.sin(xx / 37.0 + c) * np.cos(yy / 23.0)) for c in range(3)], -1)[None].astype(np.uint8)
+        rec = np.clip(gt.astype(np.int32) + rng.integers(-noise, noise + 1, gt.shape), 0, 255).astype(np.uint8)
+        got = fused.ssim(torch.from_numpy(rec).cuda(), torch.from_numpy(gt).cuda())
+        want = oracle.frame_ssim(rec, gt)
+        assert abs(got - want) <= 2e-5, (B, h, w, got, want)
+        assert abs(fused.ssim(torch.from_numpy(gt).cuda(), torch.from_numpy(gt).cuda()) - 1.0) <= 1e-6
+    # the sum is an order-free integer: two runs agree bit for bit
+    a, b = torch.from_numpy(rec).cuda(), torch.from_numpy(gt).cuda()
+    s1 = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    s2 = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    assert cabi.frame_ssim_sums(a, b, s1) == 0 and cabi.frame_ssim_sums(a, b, s2) == 0
+    assert int(s1.cpu()[0]) == int(s2.cpu()[0]) != 0
+    assert cabi.frame_ssim_sums(a[..., :2].contiguous(), b[..., :2].contiguous(), s1) == 1      # not 3 colour planes
+
+
 def test_fused_host_mirror(torch_mod, cabi, oracle):
     """`fused.py`: the reference helpers' names on the fused entry points."""
     torch = torch_mod

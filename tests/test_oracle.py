@@ -507,6 +507,42 @@ def test_frame_boundary_restatement(oracle):
     assert abs(err - 16.0 / a.size) < 1e-12 and abs(psnr - 20 * np.log10(255.0 / np.sqrt(256.0 / a.size))) < 1e-9
 
 
+def test_frame_ssim_matches_torch_formulation(oracle):
+    """The SSIM the demo reports (demo_MiddleBury.py:40-162, 382-388), written here with torch's conv2d in float32."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(23)
+    for (B, h, w) in ((1, 24, 31), (2, 11, 40), (1, 9, 30), (1, 16, 7)):
+        gt = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        rec = np.clip(gt.astype(np.int32) + rng.integers(-12, 13, gt.shape), 0, 255).astype(np.uint8)
+        X = torch.from_numpy(rec).permute(0, 3, 1, 2).reshape(B * 3, 1, h, w).float() / 255
+        Y = torch.from_numpy(gt).permute(0, 3, 1, 2).reshape(B * 3, 1, h, w).float() / 255
+        coords = torch.arange(11, dtype=torch.float32) - 5
+        g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+        g = g / g.sum()
+
+        def blur(t):
+            if t.shape[2] >= 11:
+                t = F.conv2d(t, g.view(1, 1, 11, 1))
+            if t.shape[3] >= 11:
+                t = F.conv2d(t, g.view(1, 1, 1, 11))
+            return t
+
+        mu1, mu2 = blur(X), blur(Y)
+        s1, s2, s12 = blur(X * X) - mu1 * mu1, blur(Y * Y) - mu2 * mu2, blur(X * Y) - mu1 * mu2
+        cs = (2 * s12 + 0.03 ** 2) / (s1 + s2 + 0.03 ** 2)
+        want = float((((2 * mu1 * mu2 + 0.01 ** 2) / (mu1 * mu1 + mu2 * mu2 + 0.01 ** 2)) * cs).mean())
+        got = oracle.frame_ssim(rec, gt)
+        assert abs(got - want) <= 2e-5, (got, want)
+        assert abs(oracle.frame_ssim(gt, gt) - 1.0) <= 1e-12
+    flat = np.full((1, 20, 20, 3), 200, np.uint8)
+    assert abs(oracle.frame_ssim(flat, flat) - 1.0) <= 1e-12
+    # uniform frames of different levels: structure term 1, luminance term (2ab + C1) / (a^2 + b^2 + C1)
+    other = np.full((1, 20, 20, 3), 100, np.uint8)
+    a, b = np.float64(np.float32(200) / np.float32(255)), np.float64(np.float32(100) / np.float32(255))
+    assert abs(oracle.frame_ssim(flat, other) - (2 * a * b + 1e-4) / (a * a + b * b + 1e-4)) <= 1e-9
+
+
 # ------------------------------------------------------------------ 4. golden fixtures still hold
 
 def test_golden_fixtures_reproduced(oracle, golden_dir):

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vfi_frame_u8_to_planar": [_p, _p, _i, _i, _i, _i, _i, _i, _i, Strides, _p],
     "vfi_planar_to_frame_u8": [_p, _p, _i, _i, _i, _i, _i, Strides, _p],
     "vfi_frame_error_sums": [_p, _p, ctypes.c_int64, _p, _p],
+    "vfi_frame_ssim_sums": [_p, _p, _i, _i, _i, _p, _p],
 }
 # internal entry points used by the bench / tests to time one code path in isolation
 INTERNAL_SIGNATURES = {
@@ -531,3 +532,15 @@ def frame_error_sums(a, b, sums):
     with torch.cuda.device(_dev(a, torch.uint8)):
         stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         return _finish(lib().vfi_frame_error_sums(_ptr(a), _ptr(b), a.numel(), _ptr(sums), stream))
+
+
+def frame_ssim_sums(a, b, sums):
+    """a, b: dense uint8 [B,h,w,3]; sums: int64[1] on the GPU, zeroed by the caller (2^-32 fixed point)."""
+    if a.shape != b.shape or a.dim() != 4 or a.size(3) != 3 or not a.is_contiguous() or not b.is_contiguous():
+        return 1
+    if sums.numel() < 1:
+        return 1
+    _dev(b, torch.uint8), _dev(sums, torch.int64)
+    with torch.cuda.device(_dev(a, torch.uint8)):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        return _finish(lib().vfi_frame_ssim_sums(_ptr(a), _ptr(b), a.size(0), a.size(1), a.size(2), _ptr(sums), stream))

@@ -225,6 +225,81 @@ __global__ __launch_bounds__(256) void frame_error_sums(const unsigned char* __r
         atomicAdd(&sums[threadIdx.x], part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3]);
 }
 
+// ---- SSIM of two uint8 frames as demo_MiddleBury.py:382-388 calls it: each colour plane scaled to [0,1] is one
+// single-channel image, 11-tap Gaussian (sigma 1.5) along H then along W without padding (a dimension shorter
+// than the window is left unsmoothed, :112-119), data_range 1, K = (0.01, 0.03) (:125-162).
+// One workgroup = a 32x16 tile of SSIM values of one plane: the (16+10)x(32+10) pixels of both frames go to LDS,
+// the vertical pass leaves five blurred fields (x, y, xx, yy, xy) there, the horizontal pass finishes two
+// values per thread.  Every value is added as a 2^-32 fixed-point integer: the total does not depend on the
+// order of the atomics.
+#define SSIM_TX 32
+#define SSIM_TY 16
+#define SSIM_TAPS 11
+struct SsimWindow { float wy[SSIM_TAPS], wx[SSIM_TAPS]; int ny, nx; };
+
+__global__ __launch_bounds__(256) void frame_ssim_sums(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
+                                                       int h, int w, SsimWindow win, long long* __restrict__ sums) {
+    constexpr int IW = SSIM_TX + SSIM_TAPS - 1, IH = SSIM_TY + SSIM_TAPS - 1;
+    __shared__ float px[2][IH][IW];
+    __shared__ float mid[5][SSIM_TY][IW + 1];
+    __shared__ long long part[4];
+    const int oh = h - win.ny + 1, ow = w - win.nx + 1;     // valid outputs
+    const int plane = blockIdx.z % 3, frame = blockIdx.z / 3;
+    const int x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
+    const int64_t base = (int64_t)frame * h * w * 3 + plane;
+    const int rows = min(SSIM_TY, oh - y0) + win.ny - 1, cols = min(SSIM_TX, ow - x0) + win.nx - 1;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i % IW;
+        float va = 0.0f, vb = 0.0f;
+        if (r < rows && c < cols) {
+            const int64_t o = base + ((int64_t)(y0 + r) * w + (x0 + c)) * 3;
+            va = (float)a[o] / 255.0f;                      // ToTensor: uint8 -> float32 / 255
+            vb = (float)b[o] / 255.0f;
+        }
+        px[0][r][c] = va;
+        px[1][r][c] = vb;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SSIM_TY * IW; i += 256) {
+        const int r = i / IW, c = i % IW;
+        float sx = 0.0f, sy = 0.0f, sxx = 0.0f, syy = 0.0f, sxy = 0.0f;
+        for (int k = 0; k < win.ny; ++k) {
+            const float g = win.wy[k], u = px[0][r + k][c], v = px[1][r + k][c];
+            sx = fmaf(g, u, sx);
+            sy = fmaf(g, v, sy);
+            sxx = fmaf(g, u * u, sxx);
+            syy = fmaf(g, v * v, syy);
+            sxy = fmaf(g, u * v, sxy);
+        }
+        mid[0][r][c] = sx; mid[1][r][c] = sy; mid[2][r][c] = sxx; mid[3][r][c] = syy; mid[4][r][c] = sxy;
+    }
+    __syncthreads();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    long long acc = 0;
+    for (int i = threadIdx.x; i < SSIM_TY * SSIM_TX; i += 256) {
+        const int r = i / SSIM_TX, c = i % SSIM_TX;
+        if (y0 + r >= oh || x0 + c >= ow) continue;
+        float m[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float t = 0.0f;
+            for (int k = 0; k < win.nx; ++k) t = fmaf(win.wx[k], mid[q][r][c + k], t);
+            m[q] = t;
+        }
+        const float mu1_sq = m[0] * m[0], mu2_sq = m[1] * m[1], mu12 = m[0] * m[1];
+        const float s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+        const float cs = (2.0f * s12 + C2) / (s1 + s2 + C2);
+        const float v = ((2.0f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs;
+        acc += __double2ll_rn((double)v * 4294967296.0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(sums), (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -287,5 +362,26 @@ extern "C" int vfi_frame_error_sums(const unsigned char* a, const unsigned char*
     const int64_t blocks = (n + 256 * 64 - 1) / (256 * 64);
     hipLaunchKernelGGL(frame_error_sums, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream,
                        a, b, n, sums);
+    return launch_status();
+}
+
+extern "C" int vfi_frame_ssim_sums(const unsigned char* a, const unsigned char* b, int batch, int h, int w,
+                                    long long* sums, vfi_stream_t stream) {
+    if (batch <= 0 || h <= 0 || w <= 0 || !a || !b || !sums) return VFI_ERR_SHAPE;
+    SsimWindow win;
+    double g[SSIM_TAPS], total = 0.0;
+    for (int k = 0; k < SSIM_TAPS; ++k) {                  // exp(-x^2 / (2 sigma^2)), normalised (:98-109)
+        const double x = (double)(k - SSIM_TAPS / 2);
+        g[k] = exp(-(x * x) / (2.0 * 1.5 * 1.5));
+        total += g[k];
+    }
+    for (int k = 0; k < SSIM_TAPS; ++k) win.wy[k] = win.wx[k] = (float)(g[k] / total);
+    win.ny = win.nx = SSIM_TAPS;
+    if (h < SSIM_TAPS) { win.ny = 1; win.wy[0] = 1.0f; }   // a short dimension is not smoothed (:112-119)
+    if (w < SSIM_TAPS) { win.nx = 1; win.wx[0] = 1.0f; }
+    const int oh = h - win.ny + 1, ow = w - win.nx + 1;
+    if ((int64_t)batch * 3 > 65535) return VFI_ERR_SHAPE;
+    const dim3 grid((unsigned)((ow + SSIM_TX - 1) / SSIM_TX), (unsigned)((oh + SSIM_TY - 1) / SSIM_TY), (unsigned)(batch * 3));
+    hipLaunchKernelGGL(frame_ssim_sums, grid, dim3(256), 0, (hipStream_t)stream, a, b, h, w, win, sums);
     return launch_status();
 }

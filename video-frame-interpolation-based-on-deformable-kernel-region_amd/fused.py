@@ -95,3 +95,13 @@ def interpolation_error_and_psnr(rec_u8, gt_u8):
     mse = s_sq / n
     psnr = float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
     return s_abs / n, psnr
+
+
+def ssim(rec_u8, gt_u8):
+    """Mean SSIM of uint8 frames [B,h,w,3] as `demo_MiddleBury.py:382-388` computes it (`ssim()` :40-162 on the
+    colour planes / 255: 11-tap sigma-1.5 Gaussian without padding, data_range 1)."""
+    sums = torch.zeros(1, device=rec_u8.device, dtype=torch.int64)
+    _check(cabi.frame_ssim_sums(rec_u8, gt_u8, sums), "frame_ssim_sums")
+    b, h, w, _ = rec_u8.shape
+    n = b * 3 * (h - 10 if h >= 11 else h) * (w - 10 if w >= 11 else w)
+    return int(sums.cpu()[0]) / 4294967296.0 / n
