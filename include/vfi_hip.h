@@ -214,6 +214,13 @@ int vfi_correlation_forward(const float* input1, const float* input2, float* out
                             int pad_size, int kernel_size, int max_displacement,
                             int stride1, int stride2,
                             vfi_stream_t stream);
+/* The reference's at::Half instantiation of the forward (correlation_cuda_kernel.cu:386, 403): inputs and output
+ * IEEE half, each product rounded to half, float accumulation, mean rounded to half once. */
+int vfi_correlation_forward_f16(const void* input1_half, const void* input2_half, void* output_half,
+                                int batch, int channel, int h, int w,
+                                int pad_size, int kernel_size, int max_displacement,
+                                int stride1, int stride2,
+                                vfi_stream_t stream);
 int vfi_correlation_backward(const float* input1, const float* input2, const float* gradoutput,
                              float* gradinput1, float* gradinput2,
                              int batch, int channel, int h, int w,

@@ -244,6 +244,36 @@ def correlation_fwd(f1, f2, pad=4, k=1, md=4, s1=1, s2=1, order=0, fmad=0):
     return out
 
 
+def correlation_fwd_f16(f1, f2, pad=4, k=1, md=4, s1=1, s2=1):
+    """The at::Half instantiation of the forward (correlation_cuda_kernel.cu:80-146 with scalar_t = Half): every
+    product rounded to half (:124), float accumulation in channel order, the mean rounded to half (:143).
+    numpy, vectorised over pixels; small inputs."""
+    assert f1.dtype == np.float16 and f2.dtype == np.float16
+    B, C, H, W = f1.shape
+    oc, oh, ow = correlation_out_dims(H, W, pad, k, md, s1, s2)
+    kr, dr = (k - 1) // 2, md // s2
+    dsz = 2 * dr + 1
+    p1 = np.zeros((B, C, H + 2 * pad, W + 2 * pad), np.float32)
+    p2 = np.zeros_like(p1)
+    p1[:, :, pad:pad + H, pad:pad + W] = f1
+    p2[:, :, pad:pad + H, pad:pad + W] = f2
+    out = np.zeros((B, oc, oh, ow), np.float16)
+    ys = np.arange(oh) * s1 + md
+    xs = np.arange(ow) * s1 + md
+    for tj in range(-dr, dr + 1):
+        for ti in range(-dr, dr + 1):
+            acc = np.zeros((B, oh, ow), np.float32)
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    a = p1[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    b = p2[:, :, (ys + tj * s2 + j)[:, None], (xs + ti * s2 + i)[None, :]]
+                    prod = (a * b).astype(np.float16).astype(np.float32)     # exact product, one rounding to half
+                    for c in range(C):
+                        acc = (acc + prod[:, c]).astype(np.float32)
+            out[:, (tj + dr) * dsz + (ti + dr)] = (acc / np.float32(k * k * C)).astype(np.float16)
+    return out
+
+
 def correlation_bwd(f1, f2, gout, pad=4, k=1, md=4, s1=1, s2=1):
     f1, f2, gout = _f32(f1), _f32(f2), _f32(gout)
     B, C, H, W = f1.shape

@@ -681,6 +681,27 @@ def test_frame_boundary(torch_mod, cabi, oracle):
     assert fused.interpolation_error_and_psnr(fused.padded_to_frames(x, 40, 72, padding), frames) == (0.0, float("inf"))
 
 
+def test_correlation_half(torch_mod, cabi, oracle):
+    """The reference's at::Half dispatch of correlation forward: bit-exact with the half restatement."""
+    torch = torch_mod
+    import correlation_cuda
+    rng = np.random.default_rng(37)
+    for (B, C, H, W, pad, k, md, s1, s2) in ((2, 8, 9, 11, 4, 1, 4, 1, 1), (1, 19, 18, 31, 4, 1, 4, 1, 1),
+                                              (1, 5, 12, 14, 3, 3, 2, 1, 2), (1, 3, 10, 10, 4, 1, 4, 2, 2)):
+        f1 = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        f2 = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        a, b = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+        want = oracle.correlation_fwd_f16(f1, f2, pad, k, md, s1, s2)
+        got = cabi.correlation_forward(a, b, pad, k, md, s1, s2)
+        assert got.dtype == torch.float16 and np.array_equal(got.cpu().numpy(), want)
+        # through the reference-named module: empty half tensors in, resized by the binding (correlation.py:23-25)
+        r1, r2, out = a.new_empty(0), a.new_empty(0), a.new_empty(0)
+        assert correlation_cuda.forward(a, b, r1, r2, out, pad, k, md, s1, s2, 1) == 1
+        assert out.dtype == torch.float16 and np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        correlation_cuda.forward(a, b.float(), a.new_empty(0), a.new_empty(0), a.new_empty(0), 4, 1, 4, 1, 1, 1)
+
+
 def test_frame_ssim(torch_mod, cabi, oracle):
     """SSIM as demo_MiddleBury.py:382-388 reports it; float32 on the GPU against the float64 oracle."""
     torch = torch_mod

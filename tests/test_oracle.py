@@ -230,6 +230,23 @@ def test_mindepth_c_equals_numpy_and_analytic(oracle, np_oracle):
     assert (g != 0).sum() == 2
 
 
+def test_correlation_half_restatement(oracle):
+    """at::Half instantiation: products rounded to half, float accumulation -> close to the float op on the same values."""
+    rng = np.random.default_rng(31)
+    for (C, H, W, pad, k, md, s1, s2) in ((8, 9, 11, 4, 1, 4, 1, 1), (5, 12, 14, 3, 3, 2, 1, 2), (3, 10, 10, 4, 1, 4, 2, 2)):
+        f1 = rng.standard_normal((2, C, H, W)).astype(np.float16)
+        f2 = rng.standard_normal((2, C, H, W)).astype(np.float16)
+        got = oracle.correlation_fwd_f16(f1, f2, pad, k, md, s1, s2)
+        want = oracle.correlation_fwd(f1.astype(f32), f2.astype(f32), pad, k, md, s1, s2)
+        assert got.dtype == np.float16 and got.shape == want.shape
+        assert np.abs(got.astype(f32) - want).max() <= 4e-3
+    # values whose products are exact in half: only the final rounding differs from the float op
+    f1 = (rng.integers(-8, 9, (1, 6, 9, 9)) / 4).astype(np.float16)
+    f2 = (rng.integers(-8, 9, (1, 6, 9, 9)) / 4).astype(np.float16)
+    want = oracle.correlation_fwd(f1.astype(f32), f2.astype(f32)).astype(np.float16)
+    assert np.array_equal(oracle.correlation_fwd_f16(f1, f2), want)
+
+
 def test_case8_correlation_constant(oracle):
     f = np.ones((1, 1, 10, 12), f32)
     out = oracle.correlation_fwd(f, f, 4, 1, 4, 1, 1)

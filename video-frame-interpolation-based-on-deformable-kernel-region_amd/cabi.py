@@ -50,6 +50,7 @@ SIGNATURES = {
     "vfi_correlation_output_dims": [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i),
                                     ctypes.POINTER(_i)],
     "vfi_correlation_forward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "vfi_correlation_forward_f16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "vfi_correlation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     # glue either side of the ops
     "vfi_flow_upsample4": [_p, _p, _i, _i, _i, _i, _f, _f, Strides, Strides, _p],
@@ -400,6 +401,16 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
     input1, input2 = input1.contiguous(), input2.contiguous()
     b, c, h, w = input1.shape
     oc, oh, ow = correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if input1.dtype == torch.float16:                       # the reference's at::Half instantiation
+        _dev(input1, torch.float16), _dev(input2, torch.float16)
+        output = torch.empty((b, oc, oh, ow), dtype=torch.float16, device=input1.device)
+        with torch.cuda.device(input1.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(input1.device).cuda_stream)
+            err = lib().vfi_correlation_forward_f16(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w, pad_size,
+                                                    kernel_size, max_displacement, stride1, stride2, stream)
+        if err != 0:
+            raise RuntimeError("CUDA call failed")
+        return output
     output = torch.empty((b, oc, oh, ow), dtype=torch.float32, device=input1.device)
     with torch.cuda.device(_dev(input1)):
         err = lib().vfi_correlation_forward(_ptr(input1), _ptr(input2), _ptr(output), b, c, h, w, pad_size,

@@ -19,6 +19,8 @@
 // workgroup, 9 running sums per lane), which spreads the same work over 9x more waves.
 #include "vfi_common.h"
 
+#include <hip/hip_fp16.h>
+
 namespace vfi {
 
 #define CORR_CC 8       // channels staged per LDS fill
@@ -392,6 +394,50 @@ __global__ __launch_bounds__(256) void corr_forward_generic(
     out[gid] = acc / (float)(k * k * channel);
 }
 
+// half inputs and output, the reference's `scalar_t = at::Half` instantiation (correlation_cuda_kernel.cu:386,403):
+// each product is formed in half (`rInput1[i] * rInput2[i]` on two Half values: one rounding to half, :124),
+// widened and accumulated in float; the mean is rounded to half once (:143).  One thread per output element,
+// sequential channel order, eight channels of loads in flight.
+__global__ __launch_bounds__(256) void corr_forward_generic_f16(
+    const __half* __restrict__ in1, const __half* __restrict__ in2, __half* __restrict__ out,
+    int batch, int channel, int h, int w, int oc, int oh, int ow,
+    int pad, int kr, int md, int s1, int s2, int dr) {
+    const int64_t total = (int64_t)batch * oc * oh * ow;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int ox = (int)(gid % ow);
+    const int oy = (int)((gid / ow) % oh);
+    const int tc = (int)((gid / ((int64_t)ow * oh)) % oc);
+    const int b = (int)(gid / ((int64_t)ow * oh * oc));
+    const int dsz = 2 * dr + 1;
+    const int ti = tc % dsz - dr, tj = tc / dsz - dr;
+    const int y1 = oy * s1 + md - pad, x1 = ox * s1 + md - pad;     // padded -> input coordinates
+    const int y2 = y1 + tj * s2, x2 = x1 + ti * s2;
+    const int64_t plane = (int64_t)h * w;
+    const __half* f1 = in1 + (int64_t)b * channel * plane;
+    const __half* f2 = in2 + (int64_t)b * channel * plane;
+    float acc = 0.0f;
+    for (int j = -kr; j <= kr; ++j)
+        for (int i = -kr; i <= kr; ++i) {
+            const int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+            // a tap outside either map multiplies a zero of the padding: +0 for every channel
+            if (ya < 0 || ya >= h || xa < 0 || xa >= w || yb < 0 || yb >= h || xb < 0 || xb >= w) continue;
+            const __half* pa = f1 + (int64_t)ya * w + xa;
+            const __half* pb = f2 + (int64_t)yb * w + xb;
+            int c = 0;
+            for (; c + 8 <= channel; c += 8) {
+                __half va[8], vb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { va[q] = pa[(int64_t)(c + q) * plane]; vb[q] = pb[(int64_t)(c + q) * plane]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += __half2float(__hmul(va[q], vb[q]));
+            }
+            for (; c < channel; ++c) acc += __half2float(__hmul(pa[(int64_t)c * plane], pb[(int64_t)c * plane]));
+        }
+    const int k = 2 * kr + 1;
+    out[gid] = __float2half_rn(acc / (float)(k * k * channel));
+}
+
 // backward, stride1 == 1 (correlation_cuda_kernel.cu:151-334).  One thread per input
 // element; the reference's reduction order (32 partial sums over tc = l, l+32, ...,
 // then a sequential sum of the partials) is kept.
@@ -513,6 +559,23 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
                            input2, output, batch, channel, h, w, oc, oh, ow, pad_size, kr, max_displacement, stride1,
                            stride2, dr);
     }
+    return launch_status();
+}
+
+extern "C" int vfi_correlation_forward_f16(const void* input1, const void* input2, void* output, int batch, int channel,
+                                            int h, int w, int pad_size, int kernel_size, int max_displacement,
+                                            int stride1, int stride2, vfi_stream_t stream) {
+    int oc, oh, ow;
+    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !output) return VFI_ERR_SHAPE;
+    if (vfi_correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow))
+        return VFI_ERR_SHAPE;
+    if (oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
+    const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
+    const int64_t total = (int64_t)batch * oc * oh * ow;
+    if ((total + 255) / 256 > INT_MAX) return VFI_ERR_SHAPE;
+    hipLaunchKernelGGL(corr_forward_generic_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)input1, (const __half*)input2, (__half*)output, batch, channel, h, w, oc, oh, ow,
+                       pad_size, kr, max_displacement, stride1, stride2, dr);
     return launch_status();
 }
 

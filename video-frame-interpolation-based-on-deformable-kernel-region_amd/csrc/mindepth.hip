@@ -15,7 +15,7 @@
 // backward compares the weight with `count` at all four neighbours although the forward writes
 // only the top-left one (:271-286), and leaves gradinput2 untouched (:289-326 are comments).
 #include <mutex>
-#include <vector>
+#include <deque>
 
 #include "vfi_common.h"
 
@@ -141,7 +141,7 @@ struct KeyPlane {
     unsigned long long* keys; size_t capacity;
 };
 static std::mutex g_md_mutex;
-static std::vector<KeyPlane> g_md;
+static std::deque<KeyPlane> g_md;
 
 static unsigned long long* mindepth_keys(hipStream_t st, size_t n) {
     int dev = 0;

@@ -48,7 +48,7 @@
 #include <limits.h>
 
 #include <mutex>
-#include <vector>
+#include <deque>
 
 namespace vfi {
 
@@ -604,7 +604,7 @@ struct ProjWorkspace {
     int serial;
 };
 static std::mutex g_ws_mutex;
-static std::vector<ProjWorkspace> g_ws;
+static std::deque<ProjWorkspace> g_ws;            // deque: a record handed to one caller stays put when another adds one
 
 static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_words, size_t plane_floats) {
     int dev = 0;

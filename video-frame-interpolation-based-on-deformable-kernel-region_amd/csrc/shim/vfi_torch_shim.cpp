@@ -472,8 +472,16 @@ int correlation_forward(at::Tensor& input1, at::Tensor& input2, at::Tensor& rInp
     output.resize_({batch, oc, oh, ow});
     at::Tensor a = input1.contiguous(), b = input2.contiguous();   // the reference kernels assume dense NCHW
     StreamScope s(a);
-    const int err = vfi_correlation_forward(cptr(a), cptr(b), mptr(output), batch, channel, h, w, pad_size,
-                                            kernel_size, max_displacement, stride1, stride2, s.stream);
+    int err;
+    if (a.scalar_type() == at::kHalf) {         // AT_DISPATCH_FLOATING_TYPES_AND_HALF (correlation_cuda_kernel.cu:386, 403)
+        TORCH_CHECK(b.scalar_type() == at::kHalf && output.scalar_type() == at::kHalf && a.is_cuda() && b.is_cuda() &&
+                    output.is_cuda(), "correlation_cuda.forward: half inputs need a half output on the GPU");
+        err = vfi_correlation_forward_f16(a.data_ptr(), b.data_ptr(), output.data_ptr(), batch, channel, h, w, pad_size,
+                                          kernel_size, max_displacement, stride1, stride2, s.stream);
+    } else {
+        err = vfi_correlation_forward(cptr(a), cptr(b), mptr(output), batch, channel, h, w, pad_size,
+                                      kernel_size, max_displacement, stride1, stride2, s.stream);
+    }
     TORCH_CHECK(err == VFI_OK, "CUDA call failed");
     return 1;                                   // the reference binding always returns 1 (cc:83)
 }
