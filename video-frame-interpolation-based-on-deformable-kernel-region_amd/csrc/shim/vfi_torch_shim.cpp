@@ -29,9 +29,9 @@ inline float* mptr(at::Tensor& t) { return t.data_ptr<float>(); }
 struct StreamScope {
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
     vfi_stream_t stream;
-    explicit StreamScope(const at::Tensor& t) {
+    explicit StreamScope(const at::Tensor& t, bool allow_half = false) {
         TORCH_CHECK(t.is_cuda(), "expected a GPU tensor");
-        TORCH_CHECK(t.scalar_type() == at::kFloat, "expected float32 tensors");
+        TORCH_CHECK(t.scalar_type() == at::kFloat || (allow_half && t.scalar_type() == at::kHalf), "expected float32 tensors");
         guard.set_device(t.device());
         stream = (vfi_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
     }
@@ -471,7 +471,7 @@ int correlation_forward(at::Tensor& input1, at::Tensor& input2, at::Tensor& rInp
     rInput2.resize_({batch, h + 2 * pad_size, w + 2 * pad_size, channel});
     output.resize_({batch, oc, oh, ow});
     at::Tensor a = input1.contiguous(), b = input2.contiguous();   // the reference kernels assume dense NCHW
-    StreamScope s(a);
+    StreamScope s(a, /*allow_half=*/true);
     int err;
     if (a.scalar_type() == at::kHalf) {         // AT_DISPATCH_FLOATING_TYPES_AND_HALF (correlation_cuda_kernel.cu:386, 403)
         TORCH_CHECK(b.scalar_type() == at::kHalf && output.scalar_type() == at::kHalf && a.is_cuda() && b.is_cuda() &&
