@@ -112,13 +112,14 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_blend_only(
 // and of a ones tensor; mask = (ones sample >= 0.9999); out = sample * mask.  align_corners selects
 // grid_sample's un-normalisation: 1 = torch <= 1.2 (what the reference was written for: the
 // normalisation above then round-trips to pixel + flow), 0 = the default of torch >= 1.3.
+#define PWC_CH 8                    // channels per thread: blockIdx.z = batch x channel chunks
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void pwc_warp_forward(
     const float* __restrict__ xin, const float* __restrict__ flo, float* __restrict__ out,
-    int channel, int h, int w, int align_corners, vfi_strides sx, vfi_strides sf, vfi_strides so) {
+    int channel, int groups, int h, int w, int align_corners, vfi_strides sx, vfi_strides sf, vfi_strides so) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / groups;
     const float* f = flo + (int64_t)b * sf.b + (int64_t)y * sf.h + x;
     const float vx = (float)x + f[0], vy = (float)y + f[sf.c];
     const float gx = 2.0f * vx / (float)max(w - 1, 1) - 1.0f;
@@ -141,17 +142,41 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void pwc_warp_forward(
     if (iny1 && inx0) m += wsw;
     if (iny1 && inx1) m += wse;
     const float mask = (m < 0.9999f) ? 0.0f : (m > 0.0f ? 1.0f : m);   // mask[mask<0.9999]=0; mask[mask>0]=1 (NaN stays)
-    const float* src = xin + (int64_t)b * sx.b;
-    float* dst = out + (int64_t)b * so.b + (int64_t)y * so.h + x;
-    for (int c = 0; c < channel; ++c) {
-        const float* p = src + (int64_t)c * sx.c;
-        float v = 0.0f;
-        // out_acc += value * weight, fused as nvcc fuses ATen's grid_sampler
-        if (iny0 && inx0) v = fmaf(p[(int64_t)y0 * sx.h + x0], wnw, v);
-        if (iny0 && inx1) v = fmaf(p[(int64_t)y0 * sx.h + x0 + 1], wne, v);
-        if (iny1 && inx0) v = fmaf(p[(int64_t)(y0 + 1) * sx.h + x0], wsw, v);
-        if (iny1 && inx1) v = fmaf(p[(int64_t)(y0 + 1) * sx.h + x0 + 1], wse, v);
-        dst[(int64_t)c * so.c] = v * mask;
+    // A corner outside the map is skipped by ATen; here it is read at a clamped (valid) address and both the value
+    // and its weight are replaced by 0, so v = fma(0, 0, v) = v: the same result from straight-line loads, all of a
+    // chunk's 4 x PWC_CH loads in flight at once.  (With the conditional loads of a per-channel loop a thread walked
+    // its channels one memory round trip at a time: the 196-channel 18x31 level took longer than the 32-channel
+    // 288x496 one.)
+    const int cx0 = clampi(x0, 0, w - 1), cx1 = clampi(x0 + 1, 0, w - 1), cy0 = clampi(y0, 0, h - 1), cy1 = clampi(y0 + 1, 0, h - 1);
+    const int64_t onw = (int64_t)cy0 * sx.h + cx0, one = (int64_t)cy0 * sx.h + cx1;
+    const int64_t osw = (int64_t)cy1 * sx.h + cx0, ose = (int64_t)cy1 * sx.h + cx1;
+    const bool bnw = iny0 && inx0, bne = iny0 && inx1, bsw = iny1 && inx0, bse = iny1 && inx1;
+    const float enw = bnw ? wnw : 0.0f, ene = bne ? wne : 0.0f, esw = bsw ? wsw : 0.0f, ese = bse ? wse : 0.0f;
+    const int c0 = (int)(blockIdx.z % groups) * PWC_CH;
+    const float* src = xin + (int64_t)b * sx.b + (int64_t)c0 * sx.c;
+    float* dst = out + (int64_t)b * so.b + (int64_t)c0 * so.c + (int64_t)y * so.h + x;
+    auto one_channel = [&](float pnw, float pne, float psw, float pse) {
+        float v = 0.0f;                                     // out_acc += value * weight, fused as nvcc fuses ATen's grid_sampler
+        v = fmaf(bnw ? pnw : 0.0f, enw, v);
+        v = fmaf(bne ? pne : 0.0f, ene, v);
+        v = fmaf(bsw ? psw : 0.0f, esw, v);
+        v = fmaf(bse ? pse : 0.0f, ese, v);
+        return v * mask;
+    };
+    if (c0 + PWC_CH <= channel) {
+        float q[PWC_CH][4];
+#pragma unroll
+        for (int c = 0; c < PWC_CH; ++c) {
+            const float* pl = src + (int64_t)c * sx.c;
+            q[c][0] = pl[onw]; q[c][1] = pl[one]; q[c][2] = pl[osw]; q[c][3] = pl[ose];
+        }
+#pragma unroll
+        for (int c = 0; c < PWC_CH; ++c) dst[(int64_t)c * so.c] = one_channel(q[c][0], q[c][1], q[c][2], q[c][3]);
+    } else {
+        for (int c = 0; c0 + c < channel; ++c) {
+            const float* pl = src + (int64_t)c * sx.c;
+            dst[(int64_t)c * so.c] = one_channel(pl[onw], pl[one], pl[osw], pl[ose]);
+        }
     }
 }
 
@@ -333,8 +358,12 @@ extern "C" int vfi_pwc_warp_forward(const float* x, const float* flow, float* ou
                                      int align_corners, vfi_strides sx, vfi_strides sf, vfi_strides so,
                                      vfi_stream_t stream) {
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !x || !flow || !output) return VFI_ERR_SHAPE;
-    hipLaunchKernelGGL(pwc_warp_forward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, x, flow,
-                       output, channel, h, w, align_corners ? 1 : 0, sx, sf, so);
+    const int groups = (channel + PWC_CH - 1) / PWC_CH;
+    if ((int64_t)batch * groups > 65535) return VFI_ERR_SHAPE;
+    dim3 grid = pixel_grid(w, h, batch);
+    grid.z = (unsigned)(batch * groups);
+    hipLaunchKernelGGL(pwc_warp_forward, grid, dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, x, flow,
+                       output, channel, groups, h, w, align_corners ? 1 : 0, sx, sf, so);
     return launch_status();
 }
 
