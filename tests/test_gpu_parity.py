@@ -172,6 +172,31 @@ def test_deformable_forward_bit_exact(torch_mod, cabi, oracle, variant, fs):
         assert np.array_equal(cpu(out), ref)
 
 
+def test_deformable_fast_kernel_equals_general(torch_mod, cabi, oracle):
+    """fs == 4 runs fi_forward_defor4 (tap geometry hoisted out of the channel loop); the general kernel is kept for
+    other sizes.  Same bits, on frames with taps leaving the image on every side and large learned offsets."""
+    torch = torch_mod
+    import ctypes
+    rng = np.random.default_rng(41)
+    for (B, C, H, W, sig, osig) in ((2, 5, 37, 70, 3.0, 0.7), (1, 9, 64, 130, 8.0, 3.0), (1, 3, 8, 9, 1.0, 6.0)):
+        img = rng.standard_normal((B, C, H, W)).astype(f32)
+        flow = smooth_flow(rng, B, H, W, sig) if min(H, W) >= 16 else (rng.standard_normal((B, 2, H, W)) * sig).astype(f32)
+        filt = rng.random((B, 16, H, W), dtype=f32)
+        off = (rng.standard_normal((B, 32, H, W)) * osig).astype(f32)
+        for variant in (0, 1, 2):
+            third = off if variant == 2 else filt
+            outs = []
+            for fast in (1, 0):
+                cabi.lib().vfi_debug_defor(ctypes.c_int(fast))
+                out = torch.full((B, C, H, W), float("nan"), device="cuda:0")
+                assert cabi.filterinterp_forward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, third),
+                                                       None if variant == 2 else gpu(torch, off), out) == 0
+                outs.append(out)
+            cabi.lib().vfi_debug_defor(ctypes.c_int(1))
+            assert torch.equal(outs[0], outs[1]), (variant, B, C, H, W)
+            assert np.array_equal(cpu(outs[0]), oracle.filterinterp_defor_fwd(variant, img, flow, filt, off, fmad=1))
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("fs", [4, 6, 3])
 def test_deformable_backward(torch_mod, cabi, oracle, variant, fs):

@@ -12,6 +12,8 @@
 // back to the kernel here when a tile's tap window does not fit its LDS budget.
 #include "filterinterp_dev.h"
 
+#include <limits.h>
+
 namespace vfi {
 
 // ------------------------------------------------------------------ forward, _ori
@@ -399,6 +401,16 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
     return launch_status();
 }
 
+extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* input1, const float* input2,
+                                                   const float* input3, const float* input4, float* output,
+                                                   int batch, int channel, int h, int w,
+                                                   vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                                   vfi_stream_t stream);
+
+// development knob: 0 forces the general kernel (tests compare the two)
+static int g_defor_fast = 1;
+extern "C" void vfi_debug_defor(int fast) { g_defor_fast = fast; }
+
 extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, const float* input2,
                                                const float* input3, const float* input4, float* output,
                                                int batch, int channel, int h, int w, int filter_size,
@@ -409,6 +421,12 @@ extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, 
     if (variant != VFI_DEFOR_NOFILTER && !input4) return VFI_ERR_SHAPE;
     const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
     hipStream_t st = (hipStream_t)stream;
+    if (filter_size == 4 && g_defor_fast && variant >= 0 && variant <= 2) {
+        // LDS-staged kernel (filterinterp_defor_lds.hip); -1 = not applicable
+        const int err = vfi_filterinterp_forward_defor_lds(variant, input1, input2, input3, input4, output, batch,
+                                                           channel, h, w, s1, s2, s3, s4, stream);
+        if (err >= 0) return err;
+    }
     switch (variant) {
     case VFI_DEFOR_OFFSET:
         // the reference kernel has a body for fs 4 and 6 only; other sizes leave
