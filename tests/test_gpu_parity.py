@@ -1040,6 +1040,33 @@ def test_other_baseline_sizes(torch_mod, cabi, oracle, raw):
         assert np.array_equal(cpu(a[:, [0, 63]]), ref)
 
 
+def test_full_size_1080p_deformable(torch_mod, cabi, oracle):
+    """cfg3 frame size, the deformable forwards: the LDS-staged kernel == the general gather kernel bit for bit, with
+    small learned offsets (every tile staged) and with huge ones (most tiles take the in-kernel fallback); the
+    oracle on a crop is covered by the small-frame tests."""
+    torch = torch_mod
+    import ctypes
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import synthetic as S
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    img = S.context(1, 5, H, W, gen).cuda()
+    filt = S.filters(1, H, W, gen).cuda()
+    flow = S.flow(1, H, W, 8.0, gen, "smooth").cuda()
+    for osig in (0.5, 40.0):
+        off = (torch.randn((1, 32, H, W), generator=gen) * osig).cuda()
+        for variant in (0, 1, 2):
+            outs = []
+            for fast in (1, 0):
+                cabi.lib().vfi_debug_defor(ctypes.c_int(fast))
+                out = torch.full_like(img, float("nan"))
+                assert cabi.filterinterp_forward_defor(variant, img, flow, off if variant == 2 else filt,
+                                                       None if variant == 2 else off, out) == 0
+                outs.append(out)
+            cabi.lib().vfi_debug_defor(ctypes.c_int(1))
+            assert torch.equal(outs[0], outs[1]), (osig, variant)
+
+
 def test_full_size_1080p_f16_storage(torch_mod, cabi, oracle):
     """cfg3 with fp16 storage: staged == direct to fp16 rounding on the whole 196-channel tensor,
     the direct kernel == the oracle on sampled channels."""
