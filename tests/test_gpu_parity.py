@@ -946,6 +946,75 @@ def test_wrapper_mirrors_match_cabi(torch_mod, cabi, oracle):
     assert np.array_equal(cpu(a.grad), r1) and np.array_equal(cpu(b.grad), r2)
 
 
+def test_hip_graph_capture_and_two_streams(torch_mod, cabi, oracle):
+    """The entry points only enqueue work on the caller's stream: a sequence of them can be captured into a HIP
+    graph after one warm-up call on the capture stream (the projection's per-stream workspace is allocated by that
+    call, as include/vfi_hip.h says) and replayed; two streams with their own workspaces run concurrently."""
+    torch = torch_mod
+    rng = np.random.default_rng(43)
+    B, C, H, W = 1, 6, 96, 160
+    img = gpu(torch, rng.standard_normal((B, C, H, W)).astype(f32))
+    filt = gpu(torch, rng.random((B, 16, H, W), dtype=f32))
+    flow_np = smooth_flow(rng, B, H, W, 3.0)
+    flow = gpu(torch, flow_np)
+    depth = gpu(torch, rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32))
+    f1 = gpu(torch, rng.standard_normal((B, 16, 24, 40)).astype(f32))
+    f2 = gpu(torch, rng.standard_normal((B, 16, 24, 40)).astype(f32))
+    count, proj, out = torch.empty((B, 1, H, W), device="cuda:0"), torch.empty_like(flow), torch.empty_like(img)
+
+    def sequence():
+        assert cabi.depthflowprojection_forward(flow, depth, count, proj, 1) == 0
+        assert cabi.filterinterp_forward_ori(img, proj, filt, out) == 0
+        return cabi.correlation_forward(f1, f2, 4, 1, 4, 1, 1)
+
+    corr_eager = sequence()
+    torch.cuda.synchronize()
+    want_proj, want_out, want_corr = proj.clone(), out.clone(), corr_eager.clone()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sequence()                                           # warm-up on the capture stream: workspace allocation
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        corr_graph = sequence()
+    for t in (count, proj, out, corr_graph):
+        t.fill_(float("nan"))
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(proj, want_proj) and torch.equal(out, want_out) and torch.equal(corr_graph, want_corr)
+
+    # new inputs in the same buffers: the graph recomputes from what the buffers hold at replay time
+    flow.copy_(gpu(torch, smooth_flow(rng, B, H, W, 5.0)))
+    graph.replay()
+    torch.cuda.synchronize()
+    got_proj = proj.clone()
+    sequence()
+    torch.cuda.synchronize()
+    assert torch.equal(proj, got_proj)
+
+    # two streams, each with its own projection workspace, interleaved: same results as alone
+    flows = [gpu(torch, smooth_flow(rng, B, H, W, s)) for s in (2.0, 6.0)]
+    alone = []
+    for fl in flows:
+        c, p = torch.empty_like(count), torch.empty_like(proj)
+        assert cabi.flowprojection_forward(fl, c, p, 1) == 0
+        alone.append((c, p))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    res = [(torch.empty_like(count), torch.empty_like(proj)) for _ in range(2)]
+    for rep in range(4):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                assert cabi.flowprojection_forward(flows[k], res[k][0], res[k][1], 1) == 0
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(res[k][0], alone[k][0]) and torch.equal(res[k][1], alone[k][1])
+
+
 def test_no_cpu_fallback(torch_mod):
     torch = torch_mod
     import vfidkr_amd  # noqa: F401
