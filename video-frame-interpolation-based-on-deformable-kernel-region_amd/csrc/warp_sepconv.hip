@@ -108,12 +108,29 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_forward(
         const float* p = in1 + (int64_t)b * s1.b + (int64_t)c0 * s1.c + (int64_t)y * s1.h + x;
         for (int fy = 0; fy < fs; ++fy) {
             const float t2 = vp[(int64_t)fy * s2.c];
-            for (int fx = 0; fx < fs; ++fx) {
+            const float* row = p + (int64_t)fy * s1.h;
+            int fx = 0;
+            // eight taps at a time: their 8 + 8 * CH loads are issued before the first multiply (the plain loop
+            // ran one memory round trip per tap: 1.65 TMAC/s at fs = 51); the order of the sums is unchanged
+            for (; fx + 8 <= fs; fx += 8) {
+                float t3[8], pv[8][CH];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    t3[q] = hp[(int64_t)(fx + q) * s3.c];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) pv[q][k] = (c0 + k < channel) ? row[(int64_t)k * s1.c + fx + q] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (c0 + k < channel) acc[k] = fmaf(pv[q][k] * t2, t3[q], acc[k]);
+            }
+            for (; fx < fs; ++fx) {
                 const float t3 = hp[(int64_t)fx * s3.c];
 #pragma unroll
                 for (int k = 0; k < CH; ++k)
-                    if (c0 + k < channel)
-                        acc[k] = fmaf(p[(int64_t)k * s1.c + (int64_t)fy * s1.h + fx] * t2, t3, acc[k]);
+                    if (c0 + k < channel) acc[k] = fmaf(row[(int64_t)k * s1.c + fx] * t2, t3, acc[k]);
             }
         }
 #pragma unroll
