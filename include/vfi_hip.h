@@ -143,7 +143,7 @@ int vfi_depthflowprojection_backward(const float* input1, const float* input2,
  * scheduling dependent; this library returns what those statements give when the sources are
  * visited in raster order (largest weight above the incoming `count`, first source on ties).
  * count and output must be zero-filled by the caller (untouched targets keep their values).
- * The forward keeps a per-stream scratch plane of 8 bytes per pixel.  The backward gives
+ * The forward keeps a per-stream scratch buffer of about 8.3 bytes per pixel (keys + two bitmaps).  The backward gives
  * gradinput1 only: the reference never writes gradinput2 (its code for it is commented out). */
 int vfi_mindepthflowprojection_forward(const float* input1, const float* input2,
                                        float* count, float* output,

@@ -44,6 +44,7 @@
 // arrival order), and it agrees with any fp32 summation order to rounding; addends that are
 // multiples of 2^-k (k < ~20) sum exactly in both.  count of FlowProjection is exact.
 #include "vfi_common.h"
+#include "bitwalk.h"
 
 #include <limits.h>
 
@@ -425,38 +426,6 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
 // few word loads and a count-leading/trailing-zeros; only the cell found is then read.  The cell
 // found -- hence the result -- is the same.
 struct ProjScan { int pos; float cnt; };
-
-// first set bit strictly beyond position p0 in direction dir (-1 / +1) of a bitmap line of `len`
-// bits (32 per word); -1 if none.  Words are fetched four at a time (independent loads).
-__device__ __forceinline__ int proj_bit_walk(const int* __restrict__ line, int p0, int len, int dir) {
-    const int nw = (len + 31) >> 5;
-    int wi = p0 >> 5;
-    unsigned word = (unsigned)line[wi];
-    if (dir < 0) {
-        word &= (1u << (p0 & 31)) - 1u;
-        if (word) return wi * 32 + 31 - __clz(word);
-        for (wi -= 1; wi >= 0; wi -= 4) {
-            unsigned q[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = (wi - k >= 0) ? (unsigned)line[wi - k] : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (q[k]) return (wi - k) * 32 + 31 - __clz(q[k]);
-        }
-    } else {
-        word &= ((p0 & 31) == 31) ? 0u : ~((2u << (p0 & 31)) - 1u);
-        if (word) return wi * 32 + __ffs((int)word) - 1;
-        for (wi += 1; wi < nw; wi += 4) {
-            unsigned q[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = (wi + k < nw) ? (unsigned)line[wi + k] : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (q[k]) return (wi + k) * 32 + __ffs((int)q[k]) - 1;
-        }
-    }
-    return -1;
-}
 
 // cell-by-cell walk of the reference (fallback path: no bitmaps)
 __device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn, int64_t origin, int64_t stride,
