@@ -16,10 +16,11 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern)))
+    # gpurun merges every run's output into gpurun_out/: take the newest file, not the first name
+    hits = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
     if not hits:
         raise SystemExit("missing " + pattern)
-    return hits[0]
+    return hits[-1]
 
 
 # 1. kernel stats of the profiled bench run
@@ -45,7 +46,7 @@ with open(os.path.join(dst, tag + "_bench_kernel_by_shape.csv"), "w", newline=""
 # 3. PMC means per launch of the C=196 FilterInterpolation kernel
 pmc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]   # newest run only
     if not files:
         continue
     vals = collections.defaultdict(list)
