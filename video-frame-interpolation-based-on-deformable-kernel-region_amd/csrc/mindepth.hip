@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void mindepth_award(
             nz = c != 0.0f;
         }
         const unsigned long long rowbits = __ballot(nz);
-        if (lane < 2 && y < h && blockIdx.x * 2 + lane < m.rmw)
+        if (lane < 2 && y < h && (int)blockIdx.x * 2 + lane < m.rmw)
             bits[m.rowmap + (b * h + y) * m.rmw + blockIdx.x * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
         if (nz) mine |= 1u << yl;
     }
