@@ -1015,6 +1015,57 @@ def test_hip_graph_capture_and_two_streams(torch_mod, cabi, oracle):
         assert torch.equal(res[k][0], alone[k][0]) and torch.equal(res[k][1], alone[k][1])
 
 
+def test_random_shapes_against_oracle(torch_mod, cabi, oracle):
+    """Shapes, batch sizes and flow scales drawn by hypothesis (ragged sizes around the 64-pixel tile edges, 1-pixel
+    dimensions, flows from sub-pixel to beyond the frame): every forward of the hot path against the oracle."""
+    torch = torch_mod
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 2), st.integers(1, 5), st.sampled_from([1, 3, 15, 16, 17, 33, 40]),
+           st.sampled_from([1, 2, 63, 64, 65, 100, 129]), st.sampled_from([0.0, 0.4, 3.0, 50.0]), st.integers(0, 2 ** 31 - 1))
+    def run(B, C, H, W, scale, seed):
+        rng = np.random.default_rng(seed)
+        img = rng.standard_normal((B, C, H, W)).astype(f32)
+        filt = rng.random((B, 16, H, W), dtype=f32)
+        flow = (rng.standard_normal((B, 2, H, W)) * scale).astype(f32)
+        gi, gf, gk = gpu(torch, img), gpu(torch, flow), gpu(torch, filt)
+        ref = oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1)
+        for direct in (False, True):
+            assert np.array_equal(cpu(run_fi(torch, cabi, gi, gf, gk, direct=direct)), ref)
+        off = (rng.standard_normal((B, 32, H, W)) * 0.7).astype(f32)
+        go = gpu(torch, off)
+        for variant in (0, 1, 2):
+            out = torch.full((B, C, H, W), float("nan"), device="cuda:0")
+            assert cabi.filterinterp_forward_defor(variant, gi, gf, go if variant == 2 else gk,
+                                                   None if variant == 2 else go, out) == 0
+            assert np.array_equal(cpu(out), oracle.filterinterp_defor_fwd(variant, img, flow, filt, off, fmad=1))
+        fq = (np.round(flow * 8) / 8).astype(f32)                      # dyadic: every sum exact
+        wgt = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
+        for fh in (0, 1):
+            count = torch.full((B, 1, H, W), float("nan"), device="cuda:0")
+            out = torch.full((B, 2, H, W), float("nan"), device="cuda:0")
+            assert cabi.flowprojection_forward(gpu(torch, fq), count, out, fh) == 0
+            r, rc = oracle.flowproj_fwd(fq, fh)
+            assert np.array_equal(cpu(count), rc) and np.array_equal(cpu(out), r)
+            assert cabi.depthflowprojection_forward(gpu(torch, fq), gpu(torch, wgt), count, out, fh) == 0
+            r, rc = oracle.depthflowproj_fwd(fq, wgt, fh)
+            assert np.array_equal(cpu(count), rc) and np.array_equal(cpu(out), r)
+            count.zero_(), out.zero_()
+            assert cabi.mindepthflowprojection_forward(gpu(torch, fq), gpu(torch, wgt), count, out, fh) == 0
+            r, rc = oracle.mindepthflowproj_fwd(fq, wgt, fh)
+            assert np.array_equal(cpu(count), rc) and np.array_equal(cpu(out), r)
+        warped = torch.empty_like(gi)
+        assert cabi.pwc_warp_forward(gi, gf, warped, True) == 0
+        assert np.array_equal(cpu(warped), oracle.pwc_warp(img, flow, True, fmad=1))
+        if H >= 1 and W >= 1:
+            f2 = rng.standard_normal((B, C, H, W)).astype(f32)
+            got = cabi.correlation_forward(gi, gpu(torch, f2), 4, 1, 4, 1, 1)
+            assert np.array_equal(cpu(got), oracle.correlation_fwd(img, f2, 4, 1, 4, 1, 1, order=1, fmad=1))
+
+    run()
+
+
 def test_no_cpu_fallback(torch_mod):
     torch = torch_mod
     import vfidkr_amd  # noqa: F401

@@ -560,6 +560,37 @@ def test_frame_ssim_matches_torch_formulation(oracle):
     assert abs(oracle.frame_ssim(flat, other) - (2 * a * b + 1e-4) / (a * a + b * b + 1e-4)) <= 1e-9
 
 
+# ------------------------------------------------------------------ 3b. random shapes (hypothesis): the two formulations agree
+
+def test_random_shapes_c_equals_numpy(oracle, np_oracle):
+    """Shapes and flow scales drawn by hypothesis (ragged sizes, 1-pixel dimensions, flows from sub-pixel to beyond
+    the frame): the C restatement and the independent numpy formulation agree bit for bit on every deterministic op."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 2), st.integers(1, 4), st.integers(1, 19), st.integers(1, 23), st.sampled_from([2, 3, 4, 5]),
+           st.sampled_from([0.0, 0.4, 2.5, 40.0]), st.integers(0, 2 ** 31 - 1))
+    def run(B, C, H, W, fs, scale, seed):
+        rng = np.random.default_rng(seed)
+        img = rng.standard_normal((B, C, H, W)).astype(f32)
+        filt = rng.random((B, fs * fs, H, W), dtype=f32)
+        flow = (rng.standard_normal((B, 2, H, W)) * scale).astype(f32)
+        assert np.array_equal(oracle.filterinterp_ori_fwd(img, flow, filt), np_oracle.filterinterp_ori_fwd(img, flow, filt))
+        assert np.array_equal(oracle.interp_fwd(img, flow), np_oracle.interp_fwd(img, flow))
+        # projection: dyadic flows make every sum exact, so the float64 formulation must agree bit for bit
+        fq = (np.round(flow * 8) / 8).astype(f32)
+        wgt = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
+        for fh in (0, 1):
+            a, ca = oracle.flowproj_fwd(fq, fh)
+            b, cb = np_oracle.flowproj_fwd(fq, fh)
+            assert np.array_equal(ca, cb) and np.array_equal(a, b)
+            a, ca = oracle.mindepthflowproj_fwd(fq, wgt, fh)
+            b, cb = np_oracle.mindepthflowproj_fwd(fq, wgt, fh)
+            assert np.array_equal(ca, cb) and np.array_equal(a, b)
+
+    run()
+
+
 # ------------------------------------------------------------------ 4. golden fixtures still hold
 
 def test_golden_fixtures_reproduced(oracle, golden_dir):
