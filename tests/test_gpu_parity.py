@@ -1066,6 +1066,63 @@ def test_random_shapes_against_oracle(torch_mod, cabi, oracle):
     run()
 
 
+def test_random_shapes_glue_against_oracle(torch_mod, cabi, oracle):
+    """The glue entry points on hypothesis-drawn shapes: x4 upsample, the splat fused with it, both warps +
+    blend, the uint8 frame boundary, SSIM, the half correlation."""
+    torch = torch_mod
+    from vfidkr_amd import fused
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(1, 2), st.sampled_from([1, 2, 4, 5, 9]), st.sampled_from([1, 3, 16, 17, 33]),
+           st.sampled_from([0.25, 0.5, 0.75]), st.integers(0, 2 ** 31 - 1))
+    def run(B, hq, wq, t, seed):
+        rng = np.random.default_rng(seed)
+        H, W = 4 * hq, 4 * wq
+        flow_q = (np.round(rng.standard_normal((B, 2, hq, wq)) * 8) / 64).astype(f32)        # dyadic: exact sums
+        gq = gpu(torch, flow_q)
+        up = torch.empty((B, 2, H, W), device="cuda:0")
+        assert cabi.flow_upsample4(gq, up, 16.0, t) == 0
+        assert np.array_equal(cpu(up), oracle.flow_upsample4(flow_q, 16.0, t, fmad=1))
+        depth = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
+        for fh in (0, 1):
+            for dep in (None, depth):
+                count = torch.full((B, 1, H, W), float("nan"), device="cuda:0")
+                out = torch.full((B, 2, H, W), float("nan"), device="cuda:0")
+                if dep is None:
+                    assert cabi.flowprojection_forward_up4(gq, count, out, 16.0, t, fh) == 0
+                else:
+                    assert cabi.depthflowprojection_forward_up4(gq, gpu(torch, dep), count, out, 16.0, t, fh) == 0
+                r, rc = oracle.flowproj_up4_fwd(flow_q, 16.0, t, fh, depth=dep, fmad=1)
+                assert np.array_equal(cpu(count), rc) and np.array_equal(cpu(out), r)
+        C = 3
+        ref0, ref2 = (rng.standard_normal((B, C, H, W)).astype(f32) for _ in range(2))
+        fl0, fl2 = ((rng.standard_normal((B, 2, H, W)) * 2).astype(f32) for _ in range(2))
+        k0, k2 = (rng.random((B, 16, H, W), dtype=f32) for _ in range(2))
+        blend, o0, o2 = (torch.empty((B, C, H, W), device="cuda:0") for _ in range(3))
+        assert cabi.filterinterp_blend_forward(gpu(torch, ref0), gpu(torch, ref2), gpu(torch, fl0), gpu(torch, fl2),
+                                               gpu(torch, k0), gpu(torch, k2), blend, o0, o2, 1.0 - t, t) == 0
+        rb, r0, r2 = oracle.filterinterp_blend(ref0, ref2, fl0, fl2, k0, k2, 1.0 - t, t, fmad=1)
+        assert np.array_equal(cpu(blend), rb) and np.array_equal(cpu(o0), r0) and np.array_equal(cpu(o2), r2)
+        # frames: pad, back, error sums, SSIM
+        u8 = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+        pl, pr, pt, pb = (int(v) for v in rng.integers(0, 9, 4))
+        padded = torch.empty((B, 3, H + pt + pb, W + pl + pr), device="cuda:0")
+        assert cabi.frame_u8_to_planar(torch.from_numpy(u8).cuda(), padded, pl, pr, pt, pb) == 0
+        assert np.array_equal(cpu(padded), oracle.frame_to_padded(u8, pl, pr, pt, pb))
+        back = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda:0")
+        assert cabi.planar_to_frame_u8(padded, back, pt, pl) == 0
+        assert np.array_equal(back.cpu().numpy(), u8)
+        noisy = np.clip(u8.astype(np.int32) + rng.integers(-9, 10, u8.shape), 0, 255).astype(np.uint8)
+        got = fused.ssim(torch.from_numpy(noisy).cuda(), torch.from_numpy(u8).cuda())
+        assert abs(got - oracle.frame_ssim(noisy, u8)) <= 3e-5
+        h1, h2 = (rng.standard_normal((B, 5, hq + 3, wq + 2)).astype(np.float16) for _ in range(2))
+        got = cabi.correlation_forward(torch.from_numpy(h1).cuda(), torch.from_numpy(h2).cuda(), 4, 1, 4, 1, 1)
+        assert np.array_equal(got.cpu().numpy(), oracle.correlation_fwd_f16(h1, h2, 4, 1, 4, 1, 1))
+
+    run()
+
+
 def test_no_cpu_fallback(torch_mod):
     torch = torch_mod
     import vfidkr_amd  # noqa: F401
