@@ -78,6 +78,10 @@ def build_torch_shim(force=False):
 def build_all(force=False):
     build_hip_library(force=force)
     build_torch_shim(force=force)
+    # ext/ may not have existed when the package put it on sys.path: drop the import system's cached "nothing there"
+    import importlib
+    importlib.invalidate_caches()
+    sys.path_importer_cache.pop(EXT_DIR, None)
 
 
 if __name__ == "__main__":
