@@ -61,7 +61,11 @@ def flow(b, h, w, sigma, gen, model="smooth"):
     if model == "quarter":
         q = torch.randn((b, 2, qh, qw), generator=gen, dtype=torch.float32) * sigma
     elif model == "smooth":
-        ch, cw = max(2, (h + 63) // 64 + 1), max(2, (w + 63) // 64 + 1)
+        # control points every 1/31 of the frame width (64 px at the padded 1080p width of 1984), so that the field
+        # has the same shape at every resolution: sigma and the control spacing scale together, the flow gradient
+        # (what sizes the staged windows) does not
+        cell = max(1.0, w / 31.0)
+        ch, cw = max(2, int(round(h / cell)) + 1), max(2, int(round(w / cell)) + 1)
         coarse = torch.randn((b, 2, ch, cw), generator=gen, dtype=torch.float32) * sigma
         q = F.interpolate(coarse, size=(qh, qw), mode="bicubic", align_corners=True)
     else:
