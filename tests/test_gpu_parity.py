@@ -115,6 +115,24 @@ def test_filterinterp_forward_other_filter_sizes(torch_mod, cabi, oracle, fs):
     assert np.array_equal(out, oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1))
 
 
+@pytest.mark.parametrize("fs", [2, 5, 6])
+def test_filterinterp_lds_other_filter_sizes(torch_mod, cabi, oracle, fs):
+    """fs = 2, 5, 6 (the reference's other --filter_size choices) run the LDS-staged kernel of filterinterp_lds_n.hip:
+    same bits as the direct kernel and the oracle, on ragged frames, with windows that fit and that do not."""
+    torch = torch_mod
+    rng = np.random.default_rng(50 + fs)
+    for (B, C, H, W, kind, sig) in ((2, 3, 37, 70, "smooth", 3.0), (1, 7, 64, 200, "smooth", 9.0), (1, 2, 9, 5, "rand", 2.0),
+                                    (1, 3, 40, 130, "rand", 60.0), (1, 4, 130, 131, "smooth", 0.0)):
+        img = rng.standard_normal((B, C, H, W)).astype(f32)
+        filt = rng.random((B, fs * fs, H, W), dtype=f32)
+        flow = smooth_flow(rng, B, H, W, sig) if kind == "smooth" else (rng.standard_normal((B, 2, H, W)) * sig).astype(f32)
+        gi, gf, gk = gpu(torch, img), gpu(torch, flow), gpu(torch, filt)
+        a = run_fi(torch, cabi, gi, gf, gk, direct=False)
+        b = run_fi(torch, cabi, gi, gf, gk, direct=True)
+        assert torch.equal(a, b), (fs, B, C, H, W, kind)
+        assert np.array_equal(cpu(a), oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1))
+
+
 def test_filterinterp_forward_strided_views(torch_mod, cabi, oracle):
     """batch / channel / row strides other than dense (the bindings allow any with w stride 1)."""
     torch = torch_mod

@@ -347,6 +347,10 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
 using namespace vfi;
 
 // defined in filterinterp_lds.hip; returns VFI_OK / VFI_ERR_LAUNCH, or -1 when it declines the shape
+extern "C" int vfi_filterinterp_forward_ori_lds_n(const float* input1, const float* input2, const float* input3,
+                                                   float* output, int batch, int channel, int h, int w, int fs,
+                                                   vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                                   vfi_stream_t stream);
 extern "C" int vfi_filterinterp_forward_ori_lds(const float*, const float*, const float*, float*,
                                                  int, int, int, int, vfi_strides, vfi_strides, vfi_strides,
                                                  vfi_stream_t);
@@ -377,9 +381,14 @@ extern "C" int vfi_filterinterp_forward_ori(const float* input1, const float* in
                                              vfi_stream_t stream) {
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0) return VFI_ERR_SHAPE;
     if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
-    if (fi_filter_size(filter_channels) == 4) {
+    const int fs = fi_filter_size(filter_channels);
+    if (fs == 4) {
         const int r = vfi_filterinterp_forward_ori_lds(input1, input2, input3, output, batch, channel, h, w,
                                                        s1, s2, s3, stream);
+        if (r != -1) return r;
+    } else if (fs * fs == filter_channels) {
+        const int r = vfi_filterinterp_forward_ori_lds_n(input1, input2, input3, output, batch, channel, h, w, fs,
+                                                         s1, s2, s3, stream);
         if (r != -1) return r;
     }
     return vfi_filterinterp_forward_ori_direct(input1, input2, input3, output, batch, channel, h, w,
