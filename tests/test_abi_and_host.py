@@ -187,3 +187,45 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res["total"] == 13.0
     assert sorted(res["parts"][0] + res["parts"][1]) == list(range(13))
     assert res["t"] >= 3 * 0.02 * 0.9            # rank 1 sleeps 0.02 s per step: MAX, not rank 0's 0.03 s
+
+
+# ------------------------------------------------------------------ a compiler hazard of the LDS-DMA pipelines
+
+def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
+    """The LDS-staged kernels wait for a staged window with a hand-counted `s_waitcnt vmcnt(N)`: N = the LDS-DMA
+    loads issued after it.  A register spill or reload (scratch_store / scratch_load: vector-memory operations in the
+    same counter) inside such a pipeline would make the count too lax and a window could be read before it has
+    landed -- silently.  The committed build has its few spills in the direct-gather fallback loops only; this test
+    reads the device assembly the Makefile leaves beside the objects and keeps it that way: no scratch operation in
+    any basic block that issues LDS-DMA loads, nor in any block of a loop that does."""
+    import re
+    checked = 0
+    for name in ("filterinterp_lds.s", "filterinterp_lds_n.s", "filterinterp_defor_lds.s", "filterinterp_f16.s"):
+        path = os.path.join(PKG, "lib", name)
+        assert os.path.exists(path), path
+        blocks, cur = [], None
+        for line in open(path):
+            m = re.match(r"^(\.LBB\d+_\d+):(.*)$", line)
+            if m:
+                hdr = re.search(r"Header[:=]\s*(BB\d+_\d+)", m.group(2))
+                cur = {"label": m.group(1)[2:], "loop": hdr.group(1) if hdr else None, "ins": [],
+                       "is_header": "Loop Header" in m.group(2)}
+                blocks.append(cur)
+            elif re.match(r"^_Z\w+:", line):
+                cur = None                                   # a new function: forget the block
+            elif cur is not None and re.match(r"^\s+[a-z]", line):
+                cur["ins"].append(line.strip())
+        for b in blocks:
+            if b["is_header"]:
+                b["loop"] = b["label"]
+        is_dma = lambda i: i.startswith("buffer_load") and " lds" in i      # noqa: E731
+        dma_loops = {b["loop"] for b in blocks if b["loop"] and any(is_dma(i) for i in b["ins"])}
+        for b in blocks:
+            pipelined = any(is_dma(i) for i in b["ins"]) or (b["loop"] in dma_loops)
+            if not pipelined:
+                continue
+            checked += 1
+            spills = [i for i in b["ins"] if i.startswith("scratch_")]
+            assert not spills, "%s %s: %d scratch operations inside an LDS-DMA pipeline: %s" % (
+                name, b["label"], len(spills), spills[:3])
+    assert checked >= 60                    # every K instantiation of every staged kernel was looked at
