@@ -106,9 +106,11 @@ int vfi_filterinterp_backward_defor(int variant,
 /* ---- flowprojection_cuda -----------------------------------------------------
  * replaces FlowProjectionLayer_gpu_forward / _backward (flowprojection_cuda.cc:9-57, 59-114).
  * count [B,1,H,W] and output [B,2,H,W] are fully written (no zero fill needed).
- * The forward keeps a per-stream device workspace (tile lists, bitmaps, three scratch planes:
- * about 13 bytes per pixel) that it allocates on its first call for a stream and grows on demand: make one warm-up call
- * before capturing calls into a HIP graph. */
+ * The forward keeps a per-(device, stream) workspace (block tables, bitmaps, three scratch planes: about
+ * 13 bytes per pixel), allocated on the first call for a stream and replaced by a larger one when a larger
+ * frame arrives.  hipMalloc is not legal inside a stream capture: call vfi_projection_reserve (or make one
+ * warm-up call) before capturing into a HIP graph.  A buffer that has been outgrown is retired, never freed,
+ * so a graph captured earlier stays replayable; vfi_release_workspaces() frees everything. */
 int vfi_flowprojection_forward(const float* input1, float* count, float* output,
                                int batch, int h, int w, int fillhole,
                                vfi_strides s1, vfi_strides sc,
@@ -118,6 +120,14 @@ int vfi_flowprojection_backward(const float* input1, const float* count, const f
                                 int batch, int h, int w,
                                 vfi_strides s1, vfi_strides sc,
                                 vfi_stream_t stream);
+
+/* Make the projection workspace of `stream` large enough for [batch, *, h, w] frames (both projections and
+ * their _up4 forms; h, w are the full-resolution sizes).  Allocates, so call it outside a capture. */
+int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stream);
+/* Synchronises the devices involved and frees every workspace the library holds (live and retired) on every
+ * stream.  Call only when no launch or captured graph of this library is still to run; later calls
+ * allocate afresh. */
+int vfi_release_workspaces(void);
 
 /* ---- depthflowprojection_cuda ------------------------------------------------
  * replaces DepthFlowProjectionLayer_gpu_forward / _backward

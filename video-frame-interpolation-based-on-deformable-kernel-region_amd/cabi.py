@@ -36,6 +36,8 @@ SIGNATURES = {
                                         Strides, Strides, _p],
     "vfi_flowprojection_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
     "vfi_flowprojection_backward": [_p, _p, _p, _p, _i, _i, _i, Strides, Strides, _p],
+    "vfi_projection_reserve": [_i, _i, _i, _p],
+    "vfi_release_workspaces": [],
     "vfi_depthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_depthflowprojection_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_mindepthflowprojection_forward": [_p, _p, _p, _p, _i, _i, _i, _i, Strides, Strides, Strides, _p],
@@ -229,6 +231,19 @@ def flowprojection_forward(input1, count, output, fillhole):
     with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_flowprojection_forward(_ptr(input1), _ptr(count), _ptr(output), b, h, w,
                                                         int(fillhole), _st(input1), _st(count), _stream(input1)))
+
+
+def projection_reserve(batch, h, w, device=None):
+    """Size the projection workspace of the current stream for [batch, *, h, w] frames (call before graph capture)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        return _finish(lib().vfi_projection_reserve(int(batch), int(h), int(w),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
+def release_workspaces():
+    """Free every workspace the library holds (synchronises).  Only when no launch or graph still needs them."""
+    return _finish(lib().vfi_release_workspaces())
 
 
 def flowprojection_backward(input1, count, gradoutput, gradinput1):

@@ -15,11 +15,10 @@
 // filling (:121-206) and backward (:209-331) follow the reference statement by statement; the
 // backward compares the weight with `count` at all four neighbours although the forward writes
 // only the top-left one (:271-286), and leaves gradinput2 untouched (:289-326 are comments).
-#include <mutex>
-#include <deque>
 
 #include "vfi_common.h"
 #include "bitwalk.h"
+#include "workspace.h"
 
 #include <limits.h>
 
@@ -172,32 +171,8 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void mindepth_backward(
     g[s1.c] = a1;
 }
 
-struct KeyPlane {
-    int device; hipStream_t stream;
-    unsigned long long* keys; size_t capacity;     // 8-byte words: n keys, then the bitmaps
-};
-static std::mutex g_md_mutex;
-static std::deque<KeyPlane> g_md;
-
 static unsigned long long* mindepth_keys(hipStream_t st, size_t n) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_md_mutex);
-    KeyPlane* k = nullptr;
-    for (auto& e : g_md)
-        if (e.device == dev && e.stream == st) k = &e;
-    if (!k) {
-        g_md.push_back(KeyPlane{dev, st, nullptr, 0});
-        k = &g_md.back();
-    }
-    if (k->capacity < n) {
-        if (k->keys) (void)hipFree(k->keys);                // synchronises: no kernel still uses it
-        k->keys = nullptr;
-        k->capacity = 0;
-        if (hipMalloc(&k->keys, n * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        k->capacity = n;
-    }
-    return k->keys;
+    return static_cast<unsigned long long*>(ws_get(st, WS_MINDEPTH, n * sizeof(unsigned long long), false, nullptr));
 }
 
 }  // namespace vfi

@@ -12,73 +12,82 @@
 //   3. optional hole fill from the nearest non-hole in -x, +x, -y, +y (needs the
 //      complete count plane, so it stays a separate launch).
 //
-// How (owner computes; no global atomics on the normal path): the frame is cut
-// into 64x16 tiles, used both as source tiles and as output tiles.
-//   A  proj_bin     one wave per SOURCE row segment (64 pixels of one row): bounding
-//                   box of the segment's targets -> the segment appends its id to
-//                   the list of every OUTPUT tile that box touches (~2 MB of lists
-//                   in a workspace; lists hold PROJ_LIST_CAP entries).
-//   B  proj_gather  one workgroup per OUTPUT tile: accumulates the three planes of
-//                   its tile in LDS from the row segments on its list (one wave per
-//                   segment), then writes count and the normalised flow once,
-//                   coalesced.
-//   D  proj_finish  hole filling (and, on the fallback path, normalisation)
-// Launch order A, B, D.  B (or D on the fallback path) writes every cell of count and output,
-// so callers need not zero-fill them (the reference's callers must: its splat accumulates
-// into them).
-// Fallback: when any list overflows (fields with displacements of many tiles,
-// e.g. random flow of +-W/2), B instead splats its own source tile with global
-// atomics exactly like the reference -- into three scratch planes of the workspace that
-// are zero between calls -- and D normalises them into count / output and fills holes from
-// them.  The switch is a serial number in the workspace written by A and read by B and D:
-// no host round trip, and no launch that exists only for the fallback.  (The scratch planes
-// are cleaned by the next call's A, whose workgroups see a "dirty" word.)
+// How (owner computes, pull; no global atomics on the normal path).  The frame is cut into 64x16
+// OUTPUT tiles, into 16x16 source BLOCKS and into 256x64 SUPER-tiles of 64 blocks.
+//   K0  proj_scan    one workgroup per super-tile: per block the range of integer displacements
+//                    (min/max of L - x, R - x, T - y, B - y over its valid pixels) and the largest
+//                    addends, per super-tile the box of all its targets.  Reads the flow once.
+//   K1  proj_pull    one workgroup per output tile: finds the super-tiles whose target box meets the
+//                    tile, among their blocks those that can reach it, clipped to the pixels that can;
+//                    walks the bounding rectangle U of those pixels (for a smooth field U is the tile
+//                    shifted by the flow and a few pixels larger: ~1.3 source pixels per output pixel),
+//                    accumulates in LDS and writes count and the normalised flow once, coalesced,
+//                    plus two bitmaps of "count != 0" and the tile's number of holes.
+//   K2  proj_finish  hole filling for the tiles that have holes (bitmap walks instead of the
+//                    reference's cell-by-cell walks); resets the per-call state.
+// K1 writes every cell of count and output, so callers need not zero-fill them (the reference's
+// callers must: its splat accumulates into them).  Nothing of a call's state crosses to the host:
+// the three launches are fixed, which makes a captured graph replayable.
 //
-// Accumulation in B is 64-bit fixed point (ds_add_u64): on gfx950 an LDS float atomic add
-// costs ~170 cycles per wave instruction (measured, tools/probes/lds_atomic_probe.hip), an
-// integer one ~6.  Every addend is scaled by a power of two chosen per output tile from the
-// largest |addend| that reaches it (found by A), rounded to a 32-bit integer (an error below
-// 2^-31 of that largest addend) and summed exactly in int64; the sum is converted back to
-// float once.  The result does not depend on the summation order, so it is reproducible bit
-// for bit from run to run (the reference's fp32 atomic sum carries one rounding per addend, in
-// arrival order), and it agrees with any fp32 summation order to rounding; addends that are
-// multiples of 2^-k (k < ~20) sum exactly in both.  count of FlowProjection is exact.
+// Fallback: K0 also sums how many (block, output tile) pairs there are; for fields whose blocks
+// reach many tiles each (random flow of +-W/2) K1 instead splats its own tile with global atomics
+// exactly like the reference -- into three scratch planes of the workspace that are zero between
+// calls -- and K2 normalises them into count / output and fills holes from them.  (The scratch planes
+// are cleaned by the next call's K0, whose workgroups see a "dirty" word.)
+//
+// Accumulation in K1 is fixed point in LDS integer atomics: on gfx950 an LDS float atomic add costs
+// ~170 cycles per wave instruction (tools/probes/lds_atomic_probe.hip), an integer one a few.  Every
+// addend is scaled by a power of two chosen per output tile from the largest |addend| that can reach it
+// (from K0's block table) so that it is below 2^25, rounded to an integer, and the two flow components
+// are added as ONE 64-bit integer (x << 32) + y: with at most 32 addends per cell neither half leaves
+// its 32 bits, and the halves are separated exactly afterwards.  The number of addends per cell is
+// accumulated beside it (it IS the count plane of FlowProjection); a tile with a busier cell (flows
+// converging 8-fold) is accumulated again with a correspondingly coarser scale.  Sums are exact integers,
+// so the result does not depend on the summation order -- reproducible bit for bit from run to run
+// (the reference's fp32 atomic sum carries one rounding per addend, in arrival order) -- and agrees
+// with any fp32 summation order to rounding; addends that are multiples of 2^-k (k < ~16) sum exactly
+// in both.  count of FlowProjection is exact.
 #include "vfi_common.h"
 #include "bitwalk.h"
+#include "workspace.h"
 
 #include <limits.h>
 
-#include <mutex>
-#include <deque>
-
 namespace vfi {
 
-#define PROJ_TW 64
+#define PROJ_TW 64                  // output tile
 #define PROJ_TH 16
 #define PROJ_THREADS 256
-#define PROJ_LIST_CAP 252           // source row segments per output tile before the fallback kicks in
-#define PROJ_SEG_SHIFT 12           // segment id = (batch * h + row) << 12 | tile column
+#define PROJ_BLK 16                 // source block edge
+#define PROJ_SUP_W 256              // super-tile = 16 x 4 blocks, one K0 workgroup
+#define PROJ_SUP_H 64
+#define PROJ_SUP_BLOCKS 64
+#define PROJ_SCAN_THREADS 1024
+#define PROJ_MAXHIT 64              // super-tiles listed per output tile before K1 scans all of them
+#define PROJ_ADD_BITS 25            // |scaled addend| < 2^25
+#define PROJ_ADD_CELL 32            // addends per cell that fit beside it in 32 bits
+#define PROJ_COST_LIMIT 48          // (block, tile) pairs per block, frame average, before the fallback
 
-// workspace "words" (32-bit): [0] serial of the last call whose lists overflowed; from word 16 one
-// record per output tile: [0] list length, [1] / [2] bit patterns of the largest |value addend| /
-// count addend among the listed segments (atomicMax by A), [3] unused, then PROJ_LIST_CAP segment
-// ids.  B resets words 0..2 after reading them, so a record is empty between calls.
-// workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and
-// one packed along columns (colmap[b][x][y/32]), written by B for the hole filler (A clears the
-// column-packed one, whose words are shared by two tiles); its own allocation, so its layout
-// (which depends on the frame size) cannot disturb the records.  A record's position depends on the tile index only, so calls with different frame
-// sizes can share the workspace without stale lengths.
+// workspace "words" (32-bit).  Header: [0..1] 64-bit number of (block, output tile) pairs of this call
+// (summed by K0, read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by
+// K1, read by K2 and by the next call's K0).  Then one int4 per super-tile (target box x0, y0, x1, y1;
+// x0 > x1: none), one int4 per block (dxmin | dxmax << 16, dymin | dymax << 16, bits of the largest
+// |value addend|, bits of the largest |count addend|; min > max: no valid pixel) -- block j of super-tile
+// s at index 64 s + j, so a wave reads a super-tile's blocks with one load -- and one word per output tile
+// (its number of holes).  All of it is rewritten by every call; only the header carries state.
+// workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and one packed
+// along columns (colmap[b][x][y/32]), written by K1 for the hole filler.
 #define PROJ_WS_HDR 16
-#define PROJ_WS_DIRTY 1             // header word: the scratch planes of the fallback hold sums
-#define PROJ_WS_REC (4 + PROJ_LIST_CAP)
-#define PROJ_REC_VMAX 1
-#define PROJ_REC_CMAX 2
-#define PROJ_REC_IDS 4
-static inline size_t proj_ws_tile_words(int ntiles) { return PROJ_WS_HDR + (size_t)ntiles * PROJ_WS_REC; }
+#define PROJ_WS_COST 0
+#define PROJ_WS_DIRTY 2
 
-// rmw / cmw: 32-bit words per image row / column of the two "count != 0" bitmaps;
-// rowmap / colmap: their word offsets inside the workspace's bit buffer
-struct ProjGeom { int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap; };
+// rmw / cmw: 32-bit words per image row / column of the two bitmaps; rowmap / colmap: their word offsets
+// inside the bit buffer; sup_x, sup_y, nsup: super-tiles per row / column / image; off_*: word offsets of the
+// tables inside the word buffer
+struct ProjGeom {
+    int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap;
+    int sup_x, sup_y, nsup, off_sup, off_blk, off_holes;
+};
 
 // one source pixel: validity, the four target cells (in order TL, TR, BL, BR) and the three addends
 struct ProjSplat {
@@ -201,139 +210,140 @@ __device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float*
     return proj_make<DEPTH, UP>(f, proj_load<DEPTH, UP>(f, in2, b, x, y, h, w, s2), h, w);
 }
 
-__device__ __forceinline__ int wmin(int v) { return wave_min_i32(v); }
-__device__ __forceinline__ int wmax(int v) { return wave_max_i32(v); }
 
-// A: bin source row segments into the lists of the output tiles they reach.  A workgroup covers the
-// 64x16 tile of its index: its 16 row segments first find their target rectangles (in tiles), then
-// one thread per candidate output tile reserves, with ONE returning atomic, room for all the
-// segments that reach that tile and writes their ids (a returning atomic per segment and tile
-// measured 4x slower: the round trips serialise).
-#define PROJ_BIN_CAND 64            // candidate output tiles per source tile handled by the fast path
+// min / max over each row of 16 lanes (four DPP row_shr steps); the result is in lane 15 of the row
+#define PROJ_ROW_STEP(OP, CTRL) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false))
+__device__ __forceinline__ int row16_min(int v) {
+    PROJ_ROW_STEP(min, 0x111); PROJ_ROW_STEP(min, 0x112); PROJ_ROW_STEP(min, 0x114); PROJ_ROW_STEP(min, 0x118);
+    return v;
+}
+__device__ __forceinline__ int row16_max(int v) {
+    PROJ_ROW_STEP(max, 0x111); PROJ_ROW_STEP(max, 0x112); PROJ_ROW_STEP(max, 0x114); PROJ_ROW_STEP(max, 0x118);
+    return v;
+}
+#undef PROJ_ROW_STEP
+
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int hi16(int v) { return v >> 16; }
+
+// K0: displacement ranges per 16x16 block, target box per super-tile.  A wave covers 64 x 16 pixels (four
+// blocks side by side: lane = x, 16 rows in a loop), the 16 waves of a workgroup 4 x 4 of those.
 template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(PROJ_THREADS, 8) void proj_bin(
+__global__ __launch_bounds__(PROJ_SCAN_THREADS) void proj_scan(
     ProjFlow flow, const float* __restrict__ in2, ProjGeom g, vfi_strides s2,
-    int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats, int serial) {
+    int* __restrict__ ws, float* __restrict__ planes, int64_t plane_floats) {
     if (ws[PROJ_WS_DIRTY] != 0) {
         // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
-        // a slice per workgroup (D clears the word at the end of this call)
+        // a slice per workgroup (this call's K1 rewrites the word)
         const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
         const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
-        for (int64_t i = lo + threadIdx.x; i < hi; i += PROJ_THREADS) planes[i] = 0.0f;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += PROJ_SCAN_THREADS) planes[i] = 0.0f;
     }
-    __shared__ int rect[PROJ_TH][4];                        // per row segment: tx0, ty0, tx1, ty1 (tx0 < 0: none)
-    __shared__ int tmax[2];
-    const int tile = blockIdx.x;
-    const int b = tile / (g.tiles_x * g.tiles_y);
-    const int trem = tile - b * (g.tiles_x * g.tiles_y);
-    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    __shared__ int sbox[4];
+    __shared__ int scost;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x = txi * PROJ_TW + lane;
-    // clear the column-packed bitmap words this tile shares with the tile below it (32 rows per word)
-    if ((tyi & 1) == 0 && tid < PROJ_TW && x < g.w) bits[g.colmap + (b * g.w + x) * g.cmw + (tyi >> 1)] = 0;
-    if (tid < 2) tmax[tid] = 0;
+    const int sup = blockIdx.x;
+    const int b = sup / g.nsup;
+    const int srem = sup - b * g.nsup;
+    const int sy = srem / g.sup_x, sx = srem - sy * g.sup_x;
+    if (tid < 4) sbox[tid] = tid < 2 ? INT_MAX : INT_MIN;
+    if (tid == 4) scost = 0;
     __syncthreads();
-    ProjSplat s[PROJ_TH / 4];
+    const int x = sx * PROJ_SUP_W + (wave & 3) * 64 + lane;
+    const int y0 = sy * PROJ_SUP_H + (wave >> 2) * PROJ_BLK;
+    int dxmin = INT_MAX, dxmax = INT_MIN, dymin = INT_MAX, dymax = INT_MIN, vbits = 0, cbits = 0;
+#pragma unroll 1
+    for (int r0 = 0; r0 < PROJ_BLK; r0 += 4) {
+        ProjRaw raw[4];
 #pragma unroll
-    for (int r = 0; r < PROJ_TH / 4; ++r)                   // all loads first
-        s[r] = proj_source<DEPTH, UP>(flow, in2, b, x, tyi * PROJ_TH + wave + r * 4, g.h, g.w, s2);
-    int vbits = 0, cbits = 0;
+        for (int k = 0; k < 4; ++k) raw[k] = proj_load<DEPTH, UP>(flow, in2, b, x, y0 + r0 + k, g.h, g.w, s2);
 #pragma unroll
-    for (int r = 0; r < PROJ_TH / 4; ++r) {
-        const int x0 = wmin(s[r].valid ? s[r].L : INT_MAX), x1 = wmax(s[r].valid ? s[r].R : INT_MIN);
-        const int y0 = wmin(s[r].valid ? s[r].T : INT_MAX), y1 = wmax(s[r].valid ? s[r].Bm : INT_MIN);
-        // non-negative floats order like their bit patterns
-        vbits = max(vbits, __float_as_int(s[r].valid ? fmaxf(fabsf(s[r].ax), fabsf(s[r].ay)) : 0.0f));
-        cbits = max(cbits, __float_as_int(s[r].valid ? fabsf(s[r].ac) : 0.0f));
-        if (lane == 0) {
-            int* q = rect[wave + r * 4];
-            const bool any = x0 != INT_MAX;
-            q[0] = any ? x0 / PROJ_TW : -1; q[1] = any ? y0 / PROJ_TH : 0;
-            q[2] = any ? x1 / PROJ_TW : -1; q[3] = any ? y1 / PROJ_TH : 0;
+        for (int k = 0; k < 4; ++k) {
+            const ProjSplat s = proj_make<DEPTH, UP>(flow, raw[k], g.h, g.w);
+            if (s.valid) {
+                dxmin = min(dxmin, s.L - x); dxmax = max(dxmax, s.R - x);
+                dymin = min(dymin, s.T - raw[k].y); dymax = max(dymax, s.Bm - raw[k].y);
+                // non-negative floats order like their bit patterns
+                vbits = max(vbits, __float_as_int(fmaxf(fabsf(s.ax), fabsf(s.ay))));
+                cbits = max(cbits, __float_as_int(fabsf(s.ac)));
+            }
         }
     }
-    vbits = wmax(vbits); cbits = wmax(cbits);
-    if (lane == 0) { atomicMax(&tmax[0], vbits); atomicMax(&tmax[1], cbits); }
+    dxmin = row16_min(dxmin); dxmax = row16_max(dxmax);
+    dymin = row16_min(dymin); dymax = row16_max(dymax);
+    vbits = row16_max(vbits); cbits = row16_max(cbits);
+    if ((lane & 15) == 15) {
+        const bool any = dxmin != INT_MAX;
+        int4 e;
+        e.x = any ? pack16(dxmin, dxmax) : pack16(1, 0);
+        e.y = any ? pack16(dymin, dymax) : pack16(1, 0);
+        e.z = vbits;
+        e.w = cbits;
+        const int idx = (wave >> 2) * 16 + (wave & 3) * 4 + (lane >> 4);
+        reinterpret_cast<int4*>(ws + g.off_blk)[(int64_t)sup * PROJ_SUP_BLOCKS + idx] = e;
+        if (any) {
+            const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
+            const int X0 = max(bx0 + dxmin, 0), X1 = min(bx1 + dxmax, g.w - 1);
+            const int Y0 = max(y0 + dymin, 0), Y1 = min(by1 + dymax, g.h - 1);
+            atomicMin(&sbox[0], X0); atomicMin(&sbox[1], Y0);
+            atomicMax(&sbox[2], X1); atomicMax(&sbox[3], Y1);
+            atomicAdd(&scost, (X1 / PROJ_TW - X0 / PROJ_TW + 1) * (Y1 / PROJ_TH - Y0 / PROJ_TH + 1));
+        }
+    }
     __syncthreads();
-    // union rectangle of the tile's segments
-    int cx0 = INT_MAX, cy0 = INT_MAX, cx1 = INT_MIN, cy1 = INT_MIN;
-#pragma unroll 2
-    for (int r = 0; r < PROJ_TH; ++r)
-        if (rect[r][0] >= 0) {
-            cx0 = min(cx0, rect[r][0]); cy0 = min(cy0, rect[r][1]);
-            cx1 = max(cx1, rect[r][2]); cy1 = max(cy1, rect[r][3]);
-        }
-    if (cx0 == INT_MAX) return;                             // nothing of this tile lands in the frame
-    const int nx = cx1 - cx0 + 1, ncand = nx * (cy1 - cy0 + 1);
-    const int vmax = tmax[0], cmax = tmax[1];
-    // segment id = global row << 12 | tile column: the gather splits it with a shift and a mask
-    const int seg0 = ((b * g.h + tyi * PROJ_TH) << PROJ_SEG_SHIFT) | txi;
-    for (int c = tid; c < ncand; c += PROJ_THREADS) {
-        const int ctx = cx0 + c % nx, cty = cy0 + c / nx;
-        unsigned rows = 0u;                                 // which of the 16 segments reach this output tile
-#pragma unroll 2
-        for (int r = 0; r < PROJ_TH; ++r)
-            if (rect[r][0] >= 0 && ctx >= rect[r][0] && ctx <= rect[r][2] && cty >= rect[r][1] && cty <= rect[r][3])
-                rows |= 1u << r;
-        if (!rows) continue;
-        int* rec = ws + PROJ_WS_HDR + (int64_t)((b * g.tiles_y + cty) * g.tiles_x + ctx) * PROJ_WS_REC;
-        int slot = atomicAdd(&rec[0], __popc(rows));
-        if (slot + __popc(rows) > PROJ_LIST_CAP) { ws[0] = serial; continue; }    // overflow: fallback path
-        while (rows) {
-            const int r = __ffs((int)rows) - 1;
-            rows &= rows - 1u;
-            rec[PROJ_REC_IDS + slot++] = seg0 + (r << PROJ_SEG_SHIFT);
-        }
-        if (vmax > __hip_atomic_load(&rec[PROJ_REC_VMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&rec[PROJ_REC_VMAX], vmax);
-        if (cmax > __hip_atomic_load(&rec[PROJ_REC_CMAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&rec[PROJ_REC_CMAX], cmax);
+    if (tid == 0) {
+        reinterpret_cast<int4*>(ws + g.off_sup)[sup] = make_int4(sbox[0], sbox[1], sbox[2], sbox[3]);
+        if (scost) atomicAdd(reinterpret_cast<unsigned long long*>(ws + PROJ_WS_COST), (unsigned long long)scost);
     }
 }
 
-// B: one workgroup per output tile
+// the two halves of a packed sum, exactly: S = hi * 2^32 + lo with both in int32
+__device__ __forceinline__ unsigned long long pack2(int hi, int lo) {
+    return ((unsigned long long)(unsigned)hi << 32) + (unsigned long long)(long long)lo;
+}
+__device__ __forceinline__ int packed_lo(unsigned long long s) { return (int)(unsigned)s; }
+__device__ __forceinline__ int packed_hi(unsigned long long s) {
+    return (int)((s - (unsigned long long)(long long)packed_lo(s)) >> 32);
+}
+
+template <bool DEPTH> struct ProjCountCell { typedef unsigned type; };
+template <> struct ProjCountCell<true> { typedef unsigned long long type; };    // (addends << 32) + scaled weight sum
+
+// K1: one workgroup per output tile
 template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
+__global__ __launch_bounds__(PROJ_THREADS, 8) void proj_pull(
     ProjFlow flow, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
     ProjGeom g, vfi_strides s1, vfi_strides s2, vfi_strides sc, int* __restrict__ ws, int* __restrict__ bits,
-    float* __restrict__ planes, int serial) {
-    __shared__ unsigned long long acc[3][PROJ_TH][PROJ_TW];
+    float* __restrict__ planes, unsigned long long cost_limit) {
+    typedef typename ProjCountCell<DEPTH>::type ccell;
+    __shared__ unsigned long long accv[PROJ_TH][PROJ_TW];
+    __shared__ ccell accc[PROJ_TH][PROJ_TW];
+    __shared__ int s_hits[PROJ_MAXHIT];
+    __shared__ int s_st[8];             // 0 hits, 1..4 box x0 y0 x1 y1, 5 / 6 bits of the largest addends, 7 most addends in a cell
+    __shared__ unsigned s_colm[PROJ_TW];
+    __shared__ int s_holes;
     const int tile = blockIdx.x;
-    const int b = tile / (g.tiles_x * g.tiles_y);
-    const int trem = tile - b * (g.tiles_x * g.tiles_y);
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
     const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    int* rec = ws + PROJ_WS_HDR + (int64_t)tile * PROJ_WS_REC;
-    const int* list = rec + PROJ_REC_IDS;
-    const int nsrc = min(rec[0], PROJ_LIST_CAP);
-    const int vb = rec[PROJ_REC_VMAX], cb = rec[PROJ_REC_CMAX];
-    const bool fallback = ws[0] == serial;
-    // fixed-point scales: addend * 2^k rounded to a 32-bit integer, summed in int64.  Every addend that
-    // reaches this tile is below 2^e with e from its list's maxima, so k = 30 - e keeps the product
-    // inside int32 (one v_rndne + v_cvt instead of an emulated float -> int64), and a cell can take
-    // 2^32 addends before the int64 sum overflows.  (Per output tile, so no global reduction is needed;
-    // a sum only ever mixes addends of one scale.)
-    int ev = 0, ec = 0;
-    (void)frexpf(__int_as_float(vb), &ev);
-    (void)frexpf(__int_as_float(cb), &ec);
-    // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
-    const int kv = max(-100, min(100, 30 - ev)), kc = max(-100, min(100, 30 - ec));
-    const float sv = ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);     // exact powers of two
-    __syncthreads();                                        // every thread has read the record ...
-    if (tid < 3) rec[tid] = 0;                              // ... leave it empty for the next call
+    const int ox0 = txi * PROJ_TW, oy0 = tyi * PROJ_TH;
+    const bool fallback = *reinterpret_cast<const unsigned long long*>(ws + PROJ_WS_COST) > cost_limit;
+    if (tile == 0 && tid == 0) ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;
 
     if (fallback) {
         // the reference's own scheme: this tile as SOURCE tile, global atomics into the dense scratch
         // planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
-        const int64_t npx = (int64_t)(g.ntiles / (g.tiles_x * g.tiles_y)) * g.h * g.w;
+        const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
         float* o0 = planes + (int64_t)b * g.h * g.w;
         float* o1 = o0 + npx;
         float* cn = o1 + npx;
 #pragma unroll
         for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const ProjSplat s = proj_source<DEPTH, UP>(flow, in2, b, txi * PROJ_TW + lane, tyi * PROJ_TH + wave + r * 4,
-                                                       g.h, g.w, s2);
+            const ProjSplat s = proj_source<DEPTH, UP>(flow, in2, b, ox0 + lane, oy0 + wave + r * 4, g.h, g.w, s2);
             if (!s.valid) continue;
             const int64_t oT = (int64_t)s.T * g.w, oB = (int64_t)s.Bm * g.w;
             atomicAdd(&o0[oT + s.L], s.ax); atomicAdd(&o0[oT + s.R], s.ax); atomicAdd(&o0[oB + s.L], s.ax); atomicAdd(&o0[oB + s.R], s.ax);
@@ -343,88 +353,162 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_gather(
         return;
     }
 
-    for (int i = tid; i < 3 * PROJ_TH * PROJ_TW; i += PROJ_THREADS) (&acc[0][0][0])[i] = 0ull;
+    if (tid < 8) s_st[tid] = (tid == 1 || tid == 2) ? INT_MAX : (tid == 3 || tid == 4) ? INT_MIN : 0;
+    if (tid < PROJ_TW) s_colm[tid] = 0u;
+    if (tid == 8) s_holes = 0;
+    for (int i = tid; i < PROJ_TH * PROJ_TW; i += PROJ_THREADS) { (&accv[0][0])[i] = 0ull; (&accc[0][0])[i] = 0; }
     __syncthreads();
-    const int ox0 = txi * PROJ_TW, oy0 = tyi * PROJ_TH;
-    // One wave per source row segment.  A wave first fetches all its list entries with one load
-    // (entry j of the wave sits in lane j), then walks them with the NEXT segment's pixels already in
-    // flight: no dependent list -> pixel load chain per segment.
-    const int mine = (nsrc > wave) ? (nsrc - wave + PROJ_THREADS / 64 - 1) / (PROJ_THREADS / 64) : 0;   // <= 63
-    const int ids = (lane < mine) ? list[wave + lane * (PROJ_THREADS / 64)] : 0;
-    auto fetch = [&](int j) {
-        // wave-uniform: the row arithmetic of the loads stays on the scalar unit
-        const int seg = __builtin_amdgcn_readlane(ids, j);
-        return proj_load<DEPTH, UP>(flow, in2, b, (seg & ((1 << PROJ_SEG_SHIFT) - 1)) * PROJ_TW + lane,
-                                    (seg >> PROJ_SEG_SHIFT) - b * g.h, g.h, g.w, s2);
-    };
-    ProjRaw nxt = fetch(0);                                 // lane 0 holds 0 when the wave has no entry: harmless
-    for (int j = 0; j < mine; ++j) {
-        const ProjRaw cur = nxt;
-        if (j + 1 < mine) nxt = fetch(j + 1);               // in flight while this segment is accumulated
-        const ProjSplat s = proj_make<DEPTH, UP>(flow, cur, g.h, g.w);
-        // cells of this output tile only; R == L / Bm == T at the far edges add twice (:72-73)
-        const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
-        const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
-        const bool inT = (unsigned)ty < PROJ_TH, inB = (unsigned)by < PROJ_TH;
-        // addend * 2^k is exact in float (power-of-two scale) and below 2^30 in magnitude; two's
-        // complement: adding the unsigned image of a negative int64 subtracts
-        const unsigned long long qx = (unsigned long long)(long long)__float2int_rn(s.ax * sv);
-        const unsigned long long qy = (unsigned long long)(long long)__float2int_rn(s.ay * sv);
-        const unsigned long long qc = (unsigned long long)(long long)__float2int_rn(s.ac * scn);
-        if (inT && inL) { atomicAdd(&acc[0][ty][lx], qx); atomicAdd(&acc[1][ty][lx], qy); atomicAdd(&acc[2][ty][lx], qc); }
-        if (inT && inR) { atomicAdd(&acc[0][ty][rx], qx); atomicAdd(&acc[1][ty][rx], qy); atomicAdd(&acc[2][ty][rx], qc); }
-        if (inB && inL) { atomicAdd(&acc[0][by][lx], qx); atomicAdd(&acc[1][by][lx], qy); atomicAdd(&acc[2][by][lx], qc); }
-        if (inB && inR) { atomicAdd(&acc[0][by][rx], qx); atomicAdd(&acc[1][by][rx], qy); atomicAdd(&acc[2][by][rx], qc); }
+
+    // ---- which pixels can reach this tile
+    const int tx1 = min(ox0 + PROJ_TW - 1, g.w - 1), ty1 = min(oy0 + PROJ_TH - 1, g.h - 1);
+    const int4* supt = reinterpret_cast<const int4*>(ws + g.off_sup) + (int64_t)b * g.nsup;
+    for (int s = tid; s < g.nsup; s += PROJ_THREADS) {
+        const int4 e = supt[s];
+        if (e.x <= tx1 && e.z >= ox0 && e.y <= ty1 && e.w >= oy0) {
+            const int k = atomicAdd(&s_st[0], 1);
+            if (k < PROJ_MAXHIT) s_hits[k] = s;
+        }
     }
     __syncthreads();
-    // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once; leave the two
-    // "count != 0" bitmaps for the hole filler
-    __shared__ unsigned colm[PROJ_TW];
-    if (tid < PROJ_TW) colm[tid] = 0u;
-    __syncthreads();
-    const int x = ox0 + lane;
     {
-        unsigned mine = 0u;
+        const int nhit = s_st[0];
+        const bool all = nhit > PROJ_MAXHIT;                // (then every super-tile is scanned: a superset)
+        const int nscan = all ? g.nsup : nhit;
+        const int4* blkt = reinterpret_cast<const int4*>(ws + g.off_blk) + (int64_t)b * g.nsup * PROJ_SUP_BLOCKS;
+        for (int k = wave; k < nscan; k += PROJ_THREADS / 64) {
+            const int s = all ? k : s_hits[k];
+            const int4 e = blkt[(int64_t)s * PROJ_SUP_BLOCKS + lane];
+            const int ssy = s / g.sup_x, ssx = s - ssy * g.sup_x;
+            const int bx0 = ssx * PROJ_SUP_W + (lane & 15) * PROJ_BLK, by0 = ssy * PROJ_SUP_H + (lane >> 4) * PROJ_BLK;
+            const int bx1 = min(bx0 + PROJ_BLK - 1, g.w - 1), by1 = min(by0 + PROJ_BLK - 1, g.h - 1);
+            const int dxmin = lo16(e.x), dxmax = hi16(e.x), dymin = lo16(e.y), dymax = hi16(e.y);
+            // a pixel at x reaches columns [x + dxmin, x + dxmax] at most
+            const int sx0 = max(bx0, ox0 - dxmax), sx1 = min(bx1, tx1 - dxmin);
+            const int sy0 = max(by0, oy0 - dymax), sy1 = min(by1, ty1 - dymin);
+            if (dxmin <= dxmax && sx0 <= sx1 && sy0 <= sy1) {
+                atomicMin(&s_st[1], sx0); atomicMin(&s_st[2], sy0);
+                atomicMax(&s_st[3], sx1); atomicMax(&s_st[4], sy1);
+                atomicMax(&s_st[5], e.z); atomicMax(&s_st[6], e.w);
+            }
+        }
+    }
+    __syncthreads();
+    const int ux0 = s_st[1], uy0 = s_st[2];
+    const int uw = s_st[3] - ux0 + 1, uh = s_st[3] >= ux0 ? s_st[4] - uy0 + 1 : 0;   // uh == 0: nothing lands here
+    // fixed-point scales: every addend that reaches this tile is below 2^e with e from the blocks' maxima, so
+    // addend * 2^(25 - e) is below 2^25 in magnitude
+    int ev = 0, ec = 0;
+    (void)frexpf(__int_as_float(s_st[5]), &ev);
+    (void)frexpf(__int_as_float(s_st[6]), &ec);
+    // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
+    int kv = max(-100, min(100, PROJ_ADD_BITS - ev)), kc = max(-100, min(100, PROJ_ADD_BITS - ec));
+
+    for (int attempt = 0;; ++attempt) {
+        const float sv = ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);     // exact powers of two
+        if (uh > 0) {
+            // thread i takes pixels i, i + 256, ... of U in row-major order (lanes = consecutive x); the next
+            // pixel's loads are in flight while the current one is accumulated
+            const int stepx = PROJ_THREADS % uw, stepy = PROJ_THREADS / uw;
+            int yi = tid / uw, xi = tid - yi * uw;
+            ProjRaw nxt = proj_load<DEPTH, UP>(flow, in2, b, ux0 + xi, yi < uh ? uy0 + yi : g.h, g.h, g.w, s2);
+            while (yi < uh) {
+                const ProjRaw cur = nxt;
+                xi += stepx; yi += stepy;
+                if (xi >= uw) { xi -= uw; yi += 1; }
+                nxt = proj_load<DEPTH, UP>(flow, in2, b, ux0 + xi, yi < uh ? uy0 + yi : g.h, g.h, g.w, s2);
+                const ProjSplat s = proj_make<DEPTH, UP>(flow, cur, g.h, g.w);
+                // cells of this output tile only; R == L / Bm == T at the far edges add twice (:72-73)
+                const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
+                const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
+                const bool inT = (unsigned)ty < PROJ_TH, inB = (unsigned)by < PROJ_TH;
+                // addend * 2^k is exact in float (power-of-two scale)
+                const unsigned long long qv = pack2(__float2int_rn(s.ax * sv), __float2int_rn(s.ay * sv));
+                ccell qc;
+                if constexpr (DEPTH) qc = pack2(1, __float2int_rn(s.ac * scn)); else qc = 1u;
+                if (inT && inL) { atomicAdd(&accv[ty][lx], qv); atomicAdd(&accc[ty][lx], qc); }
+                if (inT && inR) { atomicAdd(&accv[ty][rx], qv); atomicAdd(&accc[ty][rx], qc); }
+                if (inB && inL) { atomicAdd(&accv[by][lx], qv); atomicAdd(&accc[by][lx], qc); }
+                if (inB && inR) { atomicAdd(&accv[by][rx], qv); atomicAdd(&accc[by][rx], qc); }
+            }
+        }
+        __syncthreads();
+        if (attempt) break;
+        // did every cell stay within the addends its 32-bit halves can hold?
+        int nmax = 0;
 #pragma unroll
         for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const int yl = wave + r * 4;
-            const bool nz = acc[2][yl][lane] != 0ull && x < g.w && oy0 + yl < g.h;
-            const unsigned long long rowbits = __ballot(nz);
-            if (lane < 2 && oy0 + yl < g.h && txi * 2 + lane < g.rmw)
-                bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
-            if (nz) mine |= 1u << yl;
+            const ccell c = accc[wave + r * 4][lane];
+            if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, 0x7fffffffu));
         }
-        if (mine) atomicOr(&colm[lane], mine);
+        nmax = wave_max_i32(nmax);
+        if (lane == 0 && nmax > PROJ_ADD_CELL) atomicMax(&s_st[7], nmax);
+        __syncthreads();
+        nmax = s_st[7];
+        if (nmax <= PROJ_ADD_CELL) break;
+        // once more with addends small enough for the busiest cell
+        const int shift = (32 - __clz(nmax - 1)) - 5;           // ceil(log2(nmax)) - log2(32)
+        kv -= shift; kc -= shift;
+        for (int i = tid; i < PROJ_TH * PROJ_TW; i += PROJ_THREADS) { (&accv[0][0])[i] = 0ull; (&accc[0][0])[i] = 0; }
+        __syncthreads();
     }
+
+    // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once; leave the two
+    // "count != 0" bitmaps and the number of holes for the hole filler
+    const int x = ox0 + lane;
+    float cv[PROJ_TH / 4], vxv[PROJ_TH / 4], vyv[PROJ_TH / 4];
+    unsigned mine = 0u;
+    int holes = 0;
+#pragma unroll
+    for (int r = 0; r < PROJ_TH / 4; ++r) {
+        const int yl = wave + r * 4;
+        const bool inside = x < g.w && oy0 + yl < g.h;
+        // exact integer sums -> float once
+        const unsigned long long sv2 = accv[yl][lane];
+        const ccell cc = accc[yl][lane];
+        float c;
+        if constexpr (DEPTH) c = ldexpf((float)packed_lo(cc), -kc); else c = (float)cc;
+        float vx = ldexpf((float)packed_hi(sv2), -kv), vy = ldexpf((float)packed_lo(sv2), -kv);
+        if (c > 0.0f) { vx /= c; vy /= c; }
+        cv[r] = c; vxv[r] = vx; vyv[r] = vy;
+        const bool nz = inside && c != 0.0f;
+        const unsigned long long rowbits = __ballot(nz);
+        if (lane < 2 && oy0 + yl < g.h && txi * 2 + lane < g.rmw)
+            bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
+        if (nz) mine |= 1u << yl;
+        holes += __popcll(__ballot(inside && c <= 0.0f));
+    }
+    if (mine) atomicOr(&s_colm[lane], mine);
+    if (lane == 0 && holes) atomicAdd(&s_holes, holes);
     __syncthreads();
-    if (tid < PROJ_TW && colm[tid] && ox0 + tid < g.w)
-        atomicOr(&bits[g.colmap + (b * g.w + ox0 + tid) * g.cmw + (tyi >> 1)], (int)(colm[tid] << ((tyi & 1) * 16)));
+    // a column word holds two tiles' rows: each tile stores its own 16-bit half
+    if (tid < PROJ_TW && ox0 + tid < g.w)
+    {
+        unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + tid) * g.cmw) * 2;
+        half[tyi] = (unsigned short)s_colm[tid];
+        if (tyi == g.tiles_y - 1 && (tyi & 1) == 0) half[tyi + 1] = 0;     // the unused half of the last word
+    }
+    if (tid == 0) ws[g.off_holes + tile] = s_holes;
     if (x < g.w) {
 #pragma unroll
         for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const int yl = wave + r * 4, y = oy0 + yl;
+            const int y = oy0 + wave + r * 4;
             if (y >= g.h) continue;
-            // exact integer sums -> float once (through double: one rounding)
-            const float c = (float)ldexp((double)(long long)acc[2][yl][lane], -kc);
-            float vx = (float)ldexp((double)(long long)acc[0][yl][lane], -kv);
-            float vy = (float)ldexp((double)(long long)acc[1][yl][lane], -kv);
-            if (c > 0.0f) { vx /= c; vy /= c; }
             float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-            o[0] = vx;
-            o[s1.c] = vy;
-            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
+            o[0] = vxv[r];
+            o[s1.c] = vyv[r];
+            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = cv[r];
         }
     }
 }
 
-// D: pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a non-hole
+// K2: pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a non-hole
 // (never written by this pass) or is multiplied by 0.
 //
 // The reference walks cell by cell from every hole until it meets a non-zero count; along an
 // uncovered border strip that is a dependent chain of up to H (or W) loads per hole.  On the
-// normal path B has left row-packed and column-packed bitmaps of "count != 0", so a walk is a
+// normal path K1 has left row-packed and column-packed bitmaps of "count != 0", so a walk is a
 // few word loads and a count-leading/trailing-zeros; only the cell found is then read.  The cell
-// found -- hence the result -- is the same.
+// found -- hence the result -- is the same.  Tiles without holes (K1 counted them) leave at once.
 struct ProjScan { int pos; float cnt; };
 
 // cell-by-cell walk of the reference (fallback path: no bitmaps)
@@ -435,81 +519,89 @@ __device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn
     return r;
 }
 
-__global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_finish(
+__global__ __launch_bounds__(PROJ_THREADS) void proj_finish(
     float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
-    int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole, int serial) {
-    const int x = blockIdx.x * VFI_TX + threadIdx.x;
-    const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    const int b = blockIdx.z;
-    const bool fallback = ws[0] == serial;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && b == 0 && threadIdx.x == 0 && threadIdx.y == 0)
-        ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;               // read by the next call's A
-    if (x >= g.w || y >= g.h) return;
+    int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
+    const int tile = blockIdx.x;
+    const bool fallback = ws[PROJ_WS_DIRTY] != 0;
+    if (tile == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(ws + PROJ_WS_COST) = 0ull;   // K0 of the next call sums from 0
+    if (!fallback && (!fillhole || ws[g.off_holes + tile] == 0)) return;
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = txi * PROJ_TW + lane;
+    if (x >= g.w) return;
     float* o0 = out + (int64_t)b * s1.b;
     float* o1 = o0 + s1.c;
-    const int64_t row = (int64_t)y * s1.h;
-    if (fallback) {
-        // B left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
-        const int64_t npx = (int64_t)gridDim.z * g.h * g.w;
-        const float* p0 = planes + (int64_t)b * g.h * g.w;
-        const float* p1 = p0 + npx;
-        const float* pc = p1 + npx;
-        const int64_t me = (int64_t)y * g.w + x;
-        const float c = pc[me];
-        count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
-        if (c > 0.0f) {
-            o0[row + x] = p0[me] / c;
-            o1[row + x] = p1[me] / c;
-            return;
-        }
-        float v0 = 0.0f, v1 = 0.0f;
-        if (fillhole) {
-            const ProjScan l = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, -1), r = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, +1);
-            const ProjScan u = proj_walk_plain(pc, x, g.w, y, g.h, -1), d = proj_walk_plain(pc, x, g.w, y, g.h, +1);
-            if (l.cnt + r.cnt + u.cnt + d.cnt > 0.0f) {
-                const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f, rt = (r.cnt > 0.0f) ? 1.0f : 0.0f;
-                const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f, dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
-                const float den = lt + rt + ut + dt;
-                const int64_t il = (int64_t)y * g.w + l.pos, ir = (int64_t)y * g.w + r.pos;
-                const int64_t iu = (int64_t)u.pos * g.w + x, id = (int64_t)d.pos * g.w + x;
-                // a neighbour found by a walk has count > 0; the others carry weight 0 (their cell is a hole: value 0)
-                const float a0 = l.cnt > 0.0f ? p0[il] / l.cnt : 0.0f, b0 = r.cnt > 0.0f ? p0[ir] / r.cnt : 0.0f;
-                const float c0 = u.cnt > 0.0f ? p0[iu] / u.cnt : 0.0f, d0 = d.cnt > 0.0f ? p0[id] / d.cnt : 0.0f;
-                const float a1 = l.cnt > 0.0f ? p1[il] / l.cnt : 0.0f, b1 = r.cnt > 0.0f ? p1[ir] / r.cnt : 0.0f;
-                const float c1 = u.cnt > 0.0f ? p1[iu] / u.cnt : 0.0f, d1 = d.cnt > 0.0f ? p1[id] / d.cnt : 0.0f;
-                v0 = (lt * a0 + rt * b0 + ut * c0 + dt * d0) / den;
-                v1 = (lt * a1 + rt * b1 + ut * c1 + dt * d1) / den;
+#pragma unroll 1
+    for (int r = 0; r < PROJ_TH / 4; ++r) {
+        const int y = tyi * PROJ_TH + wave + r * 4;
+        if (y >= g.h) continue;
+        const int64_t row = (int64_t)y * s1.h;
+        if (fallback) {
+            // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
+            const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
+            const float* p0 = planes + (int64_t)b * g.h * g.w;
+            const float* p1 = p0 + npx;
+            const float* pc = p1 + npx;
+            const int64_t me = (int64_t)y * g.w + x;
+            const float c = pc[me];
+            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
+            if (c > 0.0f) {
+                o0[row + x] = p0[me] / c;
+                o1[row + x] = p1[me] / c;
+                continue;
             }
+            float v0 = 0.0f, v1 = 0.0f;
+            if (fillhole) {
+                const ProjScan l = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, -1), rr = proj_walk_plain(pc, (int64_t)y * g.w, 1, x, g.w, +1);
+                const ProjScan u = proj_walk_plain(pc, x, g.w, y, g.h, -1), d = proj_walk_plain(pc, x, g.w, y, g.h, +1);
+                if (l.cnt + rr.cnt + u.cnt + d.cnt > 0.0f) {
+                    const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f, rt = (rr.cnt > 0.0f) ? 1.0f : 0.0f;
+                    const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f, dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
+                    const float den = lt + rt + ut + dt;
+                    const int64_t il = (int64_t)y * g.w + l.pos, ir = (int64_t)y * g.w + rr.pos;
+                    const int64_t iu = (int64_t)u.pos * g.w + x, id = (int64_t)d.pos * g.w + x;
+                    // a neighbour found by a walk has count > 0; the others carry weight 0 (their cell is a hole: value 0)
+                    const float a0 = l.cnt > 0.0f ? p0[il] / l.cnt : 0.0f, b0 = rr.cnt > 0.0f ? p0[ir] / rr.cnt : 0.0f;
+                    const float c0 = u.cnt > 0.0f ? p0[iu] / u.cnt : 0.0f, d0 = d.cnt > 0.0f ? p0[id] / d.cnt : 0.0f;
+                    const float a1 = l.cnt > 0.0f ? p1[il] / l.cnt : 0.0f, b1 = rr.cnt > 0.0f ? p1[ir] / rr.cnt : 0.0f;
+                    const float c1 = u.cnt > 0.0f ? p1[iu] / u.cnt : 0.0f, d1 = d.cnt > 0.0f ? p1[id] / d.cnt : 0.0f;
+                    v0 = (lt * a0 + rt * b0 + ut * c0 + dt * d0) / den;
+                    v1 = (lt * a1 + rt * b1 + ut * c1 + dt * d1) / den;
+                }
+            }
+            o0[row + x] = v0;
+            o1[row + x] = v1;
+            continue;
         }
-        o0[row + x] = v0;
-        o1[row + x] = v1;
-        return;
+        const float* cn = count + (int64_t)b * sc.b;
+        if (!(cn[(int64_t)y * sc.h + x] <= 0.0f)) continue;
+        // K1 ran its normal path and left the bitmaps
+        const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
+        const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
+        const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
+        const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
+        // a walk that found nothing contributes weight 0; its position only has to be valid
+        ProjScan l, rr, u, d;
+        l.pos = xl < 0 ? x : xl; rr.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
+        l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
+        rr.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
+        u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
+        d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
+        if (l.cnt + rr.cnt + u.cnt + d.cnt <= 0.0f) continue;
+        const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
+        const float rt = (rr.cnt > 0.0f) ? 1.0f : 0.0f;
+        const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
+        const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
+        const float den = lt + rt + ut + dt;
+        o0[row + x] = (lt * o0[row + l.pos] + rt * o0[row + rr.pos] + ut * o0[(int64_t)u.pos * s1.h + x] +
+                       dt * o0[(int64_t)d.pos * s1.h + x]) / den;
+        o1[row + x] = (lt * o1[row + l.pos] + rt * o1[row + rr.pos] + ut * o1[(int64_t)u.pos * s1.h + x] +
+                       dt * o1[(int64_t)d.pos * s1.h + x]) / den;
     }
-    if (!fillhole) return;
-    const float* cn = count + (int64_t)b * sc.b;
-    if (!(cn[(int64_t)y * sc.h + x] <= 0.0f)) return;
-    // B ran its normal path and left the bitmaps
-    const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
-    const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
-    const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
-    const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
-    // a walk that found nothing contributes weight 0; its position only has to be valid
-    ProjScan l, r, u, d;
-    l.pos = xl < 0 ? x : xl; r.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
-    l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
-    r.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
-    u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
-    d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
-    if (l.cnt + r.cnt + u.cnt + d.cnt <= 0.0f) return;
-    const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
-    const float rt = (r.cnt > 0.0f) ? 1.0f : 0.0f;
-    const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
-    const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
-    const float den = lt + rt + ut + dt;
-    o0[row + x] = (lt * o0[row + l.pos] + rt * o0[row + r.pos] + ut * o0[(int64_t)u.pos * s1.h + x] +
-                   dt * o0[(int64_t)d.pos * s1.h + x]) / den;
-    o1[row + x] = (lt * o1[row + l.pos] + rt * o1[row + r.pos] + ut * o1[(int64_t)u.pos * s1.h + x] +
-                   dt * o1[(int64_t)d.pos * s1.h + x]) / den;
 }
 
 template <bool DEPTH>
@@ -561,59 +653,42 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_backward(
     }
 }
 
-// Per (device, stream) workspace for the tile lists, allocated on first use and grown on demand.
-// hipMalloc happens on the first call for a given stream / a larger frame only (do a warm-up call
-// before capturing into a graph); calls on one stream are ordered, so one workspace per stream is
-// enough and two streams never share one.
-struct ProjWorkspace {
-    int device; hipStream_t stream;
-    int* words; size_t capacity;
-    int* bits; size_t bit_capacity;
-    float* planes; size_t plane_capacity;       // fallback scratch: 3 dense planes, zero between calls
-    int serial;
-};
-static std::mutex g_ws_mutex;
-static std::deque<ProjWorkspace> g_ws;            // deque: a record handed to one caller stays put when another adds one
+// Geometry and workspace sizes of a call; false when the frame is beyond what the tables can index.
+struct ProjSizes { size_t words, bit_words, plane_floats; };
+static bool proj_geometry(int batch, int h, int w, ProjGeom* g, ProjSizes* z) {
+    if (batch <= 0 || h <= 0 || w <= 0 || h > 32767 || w > 32767) return false;    // displacements are stored as int16
+    g->h = h; g->w = w;
+    g->tiles_x = (w + PROJ_TW - 1) / PROJ_TW;
+    g->tiles_y = (h + PROJ_TH - 1) / PROJ_TH;
+    const int64_t nt = (int64_t)g->tiles_x * g->tiles_y * batch;
+    g->sup_x = (w + PROJ_SUP_W - 1) / PROJ_SUP_W;
+    g->sup_y = (h + PROJ_SUP_H - 1) / PROJ_SUP_H;
+    g->nsup = g->sup_x * g->sup_y;
+    const int64_t ns = (int64_t)g->nsup * batch;
+    if (nt > (1 << 24) || ns > (1 << 22)) return false;
+    g->ntiles = (int)nt;
+    g->rmw = (w + 31) / 32;
+    g->cmw = (g->tiles_y * PROJ_TH + 31) / 32;              // whole tiles: K1 stores 16-bit halves
+    z->bit_words = (size_t)batch * ((size_t)h * g->rmw + (size_t)w * g->cmw);
+    if (z->bit_words > (size_t)INT_MAX) return false;
+    g->rowmap = 0;
+    g->colmap = batch * h * g->rmw;
+    g->off_sup = PROJ_WS_HDR;
+    g->off_blk = g->off_sup + 4 * (int)ns;
+    g->off_holes = g->off_blk + 4 * PROJ_SUP_BLOCKS * (int)ns;
+    z->words = (size_t)g->off_holes + (size_t)nt;
+    z->plane_floats = (size_t)3 * batch * h * w;
+    return true;
+}
 
-static ProjWorkspace* proj_workspace(hipStream_t st, size_t words, size_t bit_words, size_t plane_floats) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    ProjWorkspace* w = nullptr;
-    for (auto& e : g_ws)
-        if (e.device == dev && e.stream == st) w = &e;
-    if (!w) {
-        g_ws.push_back(ProjWorkspace{dev, st, nullptr, 0, nullptr, 0, nullptr, 0, 0});
-        w = &g_ws.back();
-    }
-    if (w->capacity < words) {
-        if (w->words) (void)hipFree(w->words);              // synchronises: no kernel still uses it
-        w->words = nullptr;
-        w->capacity = 0;
-        if (hipMalloc(&w->words, words * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(w->words, 0, words * sizeof(int)) != hipSuccess) return nullptr;
-        w->capacity = words;
-        w->serial = 0;
-        // the "dirty" word went with the old header: make the scratch planes clean by hand
-        if (w->planes && hipMemset(w->planes, 0, w->plane_capacity * sizeof(float)) != hipSuccess) return nullptr;
-    }
-    if (w->bit_capacity < bit_words) {
-        if (w->bits) (void)hipFree(w->bits);
-        w->bits = nullptr;
-        w->bit_capacity = 0;
-        if (hipMalloc(&w->bits, bit_words * sizeof(int)) != hipSuccess) return nullptr;
-        w->bit_capacity = bit_words;                        // A clears what a call uses
-    }
-    if (w->plane_capacity < plane_floats) {
-        if (w->planes) (void)hipFree(w->planes);
-        w->planes = nullptr;
-        w->plane_capacity = 0;
-        if (hipMalloc(&w->planes, plane_floats * sizeof(float)) != hipSuccess) return nullptr;
-        if (hipMemset(w->planes, 0, plane_floats * sizeof(float)) != hipSuccess) return nullptr;
-        w->plane_capacity = plane_floats;
-    }
-    w->serial += 1;                                         // serial 0 never matches: the header starts at 0
-    return w;
+struct ProjBuffers { int* words; int* bits; float* planes; };
+static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
+    // the header and the scratch planes carry state between calls and start at zero; the tables and the
+    // bitmaps are rewritten by every call
+    p->words = static_cast<int*>(ws_get(st, WS_PROJ_WORDS, z.words * sizeof(int), true, nullptr));
+    p->bits = static_cast<int*>(ws_get(st, WS_PROJ_BITS, z.bit_words * sizeof(int), false, nullptr));
+    p->planes = static_cast<float*>(ws_get(st, WS_PROJ_PLANES, z.plane_floats * sizeof(float), true, nullptr));
+    return p->words && p->bits && p->planes;
 }
 
 // s1 = strides of `out` (the reference binding shares them with the input flow)
@@ -621,31 +696,21 @@ template <bool DEPTH, bool UP>
 static int project_forward(const ProjFlow& flow, const float* in2, float* count, float* out, int batch, int h, int w,
                            int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
     ProjGeom g;
-    g.h = h; g.w = w;
-    g.tiles_x = (w + PROJ_TW - 1) / PROJ_TW;
-    g.tiles_y = (h + PROJ_TH - 1) / PROJ_TH;
-    const int64_t nt = (int64_t)g.tiles_x * g.tiles_y * batch;
-    if (nt > (1 << 24) || g.tiles_x > (1 << PROJ_SEG_SHIFT) || (int64_t)batch * h >= (1 << (31 - PROJ_SEG_SHIFT)))
-        return VFI_ERR_SHAPE;
-    g.ntiles = (int)nt;
-    g.rmw = (w + 31) / 32;
-    g.cmw = (g.tiles_y * PROJ_TH + 31) / 32;                // whole tiles: B ORs 16-bit halves
-    const size_t tile_words = proj_ws_tile_words(g.ntiles);
-    const size_t bit_words = (size_t)batch * ((size_t)h * g.rmw + (size_t)w * g.cmw);
-    if (bit_words > (size_t)INT_MAX) return VFI_ERR_SHAPE;
-    g.rowmap = 0;
-    g.colmap = batch * h * g.rmw;
-    ProjWorkspace* ws = proj_workspace(st, tile_words, bit_words, (size_t)3 * batch * h * w);
-    if (!ws) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL((proj_bin<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, g, s2, ws->words,
-                       ws->bits, ws->planes, (int64_t)ws->plane_capacity, ws->serial);
+    ProjSizes z;
+    if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
+    ProjBuffers p;
+    if (!proj_buffers(st, z, &p)) return VFI_ERR_LAUNCH;
+    const int nsup_all = g.nsup * batch;
+    const unsigned long long cost_limit = (unsigned long long)PROJ_COST_LIMIT * PROJ_SUP_BLOCKS * (unsigned long long)nsup_all;
+    hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(nsup_all), dim3(PROJ_SCAN_THREADS), 0, st, flow, in2, g, s2, p.words,
+                       p.planes, (int64_t)z.plane_floats);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL((proj_gather<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, count, out, g, s1,
-                       s2, sc, ws->words, ws->bits, ws->planes, ws->serial);
+    hipLaunchKernelGGL((proj_pull<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, count, out, g, s1,
+                       s2, sc, p.words, p.bits, p.planes, cost_limit);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    // (also runs with fillhole == 0: it is where the fallback path normalises)
-    hipLaunchKernelGGL(proj_finish, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, st, count, out, g, s1, sc,
-                       ws->words, ws->bits, ws->planes, fillhole, ws->serial);
+    // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
+    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, count, out, g, s1, sc, p.words, p.bits,
+                       p.planes, fillhole);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return VFI_OK;
 }
@@ -667,6 +732,14 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void flow_upsample4(
 }  // namespace vfi
 
 using namespace vfi;
+
+extern "C" int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stream) {
+    ProjGeom g;
+    ProjSizes z;
+    if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
+    ProjBuffers p;
+    return proj_buffers((hipStream_t)stream, z, &p) ? VFI_OK : VFI_ERR_LAUNCH;
+}
 
 extern "C" int vfi_flowprojection_forward(const float* input1, float* count, float* output, int batch, int h, int w,
                                            int fillhole, vfi_strides s1, vfi_strides sc, vfi_stream_t stream) {
