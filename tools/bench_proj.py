@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import vfidkr_amd  # noqa: E402,F401
+if "--lib" in sys.argv:         # a development build of the library (make OUT=... EXTRA=...)
+    vfidkr_amd.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from vfidkr_amd import cabi, synthetic as S  # noqa: E402
 
 
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--fillhole", type=int, default=1)
+    ap.add_argument("--lib", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     h, w = S.padded_size(args.height, args.width)

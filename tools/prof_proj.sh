@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/projtrace_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_proj.py --flows $FLOWS --iters 50 > $OUT/run.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/bench_proj.py --flows $FLOWS --iters 50 $3 $4 > $OUT/run.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]

@@ -13,40 +13,38 @@
 //      complete count plane, so it stays a separate launch).
 //
 // How (owner computes, pull; no global atomics on the normal path).  The frame is cut into 64x16
-// OUTPUT tiles, into 16x16 source BLOCKS and into 256x64 SUPER-tiles of 64 blocks.
-//   K0  proj_scan    one workgroup per super-tile: per block the range of integer displacements
-//                    (min/max of L - x, R - x, T - y, B - y over its valid pixels) and the largest
-//                    addends, per super-tile the box of all its targets.  Reads the flow once.
-//   K1  proj_pull    one workgroup per output tile: finds the super-tiles whose target box meets the
-//                    tile, among their blocks those that can reach it, clipped to the pixels that can;
-//                    walks the bounding rectangle U of those pixels (for a smooth field U is the tile
-//                    shifted by the flow and a few pixels larger: ~1.3 source pixels per output pixel),
-//                    accumulates in LDS and writes count and the normalised flow once, coalesced,
-//                    plus two bitmaps of "count != 0" and the tile's number of holes.
-//   K2  proj_finish  hole filling for the tiles that have holes (bitmap walks instead of the
+// OUTPUT tiles and, as a source, into 16x16 BLOCKS.
+//   K0  proj_scan    reads the flow once: per block the range of its integer displacements and its largest
+//                    addends; for every output tile the block can reach, the part of the block that can reach
+//                    it is merged into that tile's SOURCE RECTANGLE (a few atomicMax on a 32-byte record).
+//   K1  proj_pull    one workgroup per output tile: walks its source rectangle (for a smooth field: the tile
+//                    shifted by the flow and a few pixels larger, ~1.3 source pixels per output pixel),
+//                    accumulates in LDS and writes count and the normalised flow once, coalesced, plus two
+//                    bitmaps of "count != 0"; lists the tile if it has holes.
+//   K2  proj_finish  hole filling for the listed tiles (bitmap searches in registers instead of the
 //                    reference's cell-by-cell walks); resets the per-call state.
 // K1 writes every cell of count and output, so callers need not zero-fill them (the reference's
-// callers must: its splat accumulates into them).  Nothing of a call's state crosses to the host:
-// the three launches are fixed, which makes a captured graph replayable.
+// callers must: its splat accumulates into them).  Nothing of a call's state crosses to the host and
+// no kernel argument changes from call to call: a captured graph is replayable.
 //
-// Fallback: K0 also sums how many (block, output tile) pairs there are; for fields whose blocks
-// reach many tiles each (random flow of +-W/2) K1 instead splats its own tile with global atomics
-// exactly like the reference -- into three scratch planes of the workspace that are zero between
-// calls -- and K2 normalises them into count / output and fills holes from them.  (The scratch planes
-// are cleaned by the next call's K0, whose workgroups see a "dirty" word.)
+// Fallback: a block whose pixels scatter over more than PROJ_BLOCK_CAP output tiles (random flow of
+// +-W/2) raises a flag in K0; K1 then splats its own tile with global atomics exactly like the
+// reference -- into three scratch planes of the workspace that are zero between calls -- and K2
+// normalises them into count / output and fills holes from them.  (The scratch planes are cleaned by
+// the next call's K0, whose workgroups see a "dirty" word.)
 //
 // Accumulation in K1 is fixed point in LDS integer atomics: on gfx950 an LDS float atomic add costs
 // ~170 cycles per wave instruction (tools/probes/lds_atomic_probe.hip), an integer one a few.  Every
 // addend is scaled by a power of two chosen per output tile from the largest |addend| that can reach it
-// (from K0's block table) so that it is below 2^25, rounded to an integer, and the two flow components
-// are added as ONE 64-bit integer (x << 32) + y: with at most 32 addends per cell neither half leaves
-// its 32 bits, and the halves are separated exactly afterwards.  The number of addends per cell is
-// accumulated beside it (it IS the count plane of FlowProjection); a tile with a busier cell (flows
-// converging 8-fold) is accumulated again with a correspondingly coarser scale.  Sums are exact integers,
-// so the result does not depend on the summation order -- reproducible bit for bit from run to run
-// (the reference's fp32 atomic sum carries one rounding per addend, in arrival order) -- and agrees
-// with any fp32 summation order to rounding; addends that are multiples of 2^-k (k < ~16) sum exactly
-// in both.  count of FlowProjection is exact.
+// (K0) so that it is below 2^25, rounded to an integer, and the two flow components are added as ONE
+// 64-bit integer (x << 32) + y: with at most 32 addends per cell neither half leaves its 32 bits, and
+// the halves are separated exactly afterwards.  The number of addends per cell is accumulated beside it
+// (it IS the count plane of FlowProjection); a tile with a busier cell (flows converging 8-fold) is
+// accumulated again with a correspondingly coarser scale.  Sums are exact integers, so the result does
+// not depend on the summation order -- reproducible bit for bit from run to run (the reference's fp32
+// atomic sum carries one rounding per addend, in arrival order) -- and agrees with any fp32 summation
+// order to rounding; addends that are multiples of 2^-k (k < ~16) sum exactly in both.  count of
+// FlowProjection is exact.
 #include "vfi_common.h"
 #include "bitwalk.h"
 #include "workspace.h"
@@ -59,50 +57,41 @@ namespace vfi {
 #define PROJ_TH 16
 #define PROJ_THREADS 256
 #define PROJ_BLK 16                 // source block edge
-#define PROJ_SUP_W 256              // super-tile = 16 x 4 blocks, one K0 workgroup
-#define PROJ_SUP_H 64
-#define PROJ_SUP_BLOCKS 64
-#define PROJ_SCAN_THREADS 1024
-#define PROJ_MAXHIT 64              // super-tiles listed per output tile before K1 scans all of them
 #define PROJ_ADD_BITS 25            // |scaled addend| < 2^25
 #define PROJ_ADD_CELL 32            // addends per cell that fit beside it in 32 bits
-#define PROJ_COST_LIMIT 48          // (block, tile) pairs per block, frame average, before the fallback
+#define PROJ_BLOCK_CAP 64           // output tiles one block may reach before the call takes the fallback
 
-// workspace "words" (32-bit).  Header: [0..1] 64-bit number of (block, output tile) pairs of this call
-// (summed by K0, read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by
-// K1, read by K2 and by the next call's K0).  Then one int4 per super-tile (target box x0, y0, x1, y1;
-// x0 > x1: none), one int4 per block (dxmin | dxmax << 16, dymin | dymax << 16, bits of the largest
-// |value addend|, bits of the largest |count addend|; min > max: no valid pixel) -- block j of super-tile
-// s at index 64 s + j, so a wave reads a super-tile's blocks with one load -- and one word per output tile
-// (its number of holes).  All of it is rewritten by every call; only the header carries state.
+// workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
+// read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by K1, read by K2 and by
+// the next call's K0); [3] length of the list of tiles with holes (reset by K0, appended by K1, read by K2).
+// Then one 8-word record per output tile: its source rectangle as 32767 - x0, 32767 - y0, x1 + 1, y1 + 1 and
+// the bits of the largest |value addend| and |count addend| that reach it -- all merged with atomicMax by K0,
+// so 0 = nothing; K1 reads its record and zeroes it again.  Then the list of tiles with holes.
 // workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and one packed
-// along columns (colmap[b][x][y/32]), written by K1 for the hole filler.
+// along columns (colmap[b][x][y/32], lines padded to whole 16-byte groups), written by K1 for the hole filler.
 #define PROJ_WS_HDR 16
-#define PROJ_WS_COST 0
+#define PROJ_WS_FLAG 0
 #define PROJ_WS_DIRTY 2
+#define PROJ_WS_NLIST 3
+#define PROJ_TILE_WORDS 8
 
 // rmw / cmw: 32-bit words per image row / column of the two bitmaps; rowmap / colmap: their word offsets
-// inside the bit buffer; sup_x, sup_y, nsup: super-tiles per row / column / image; off_*: word offsets of the
-// tables inside the word buffer
+// inside the bit buffer; off_tile / off_list: word offsets of the tile records and of the hole list
 struct ProjGeom {
-    int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap;
-    int sup_x, sup_y, nsup, off_sup, off_blk, off_holes;
-};
-
-// one source pixel: validity, the four target cells (in order TL, TR, BL, BR) and the three addends
-struct ProjSplat {
-    bool valid;
-    int L, T, R, Bm;
-    float ax, ay, ac;
+    int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap, off_tile, off_list;
 };
 
 // Where the flow of a source pixel comes from.  UP == false: the full-resolution flow tensor of the
 // reference's FlowProjection.  UP == true: the network's quarter-resolution flow; the pixel's flow is
 // nn.Upsample(scale_factor=4, mode='bilinear') of (m0 * flow) * m1, formed on the fly -- the x4
 // upsampled tensor of forward_flownets (networks/DAIN_slowmotion.py:204-216) is never materialised.
-struct ProjFlow {
-    const float* p;
-    vfi_strides s;
+// Row strides are 32-bit here (the host checks that every in-plane offset fits): the kernels address a
+// plane as uniform base + 32-bit offset.
+struct ProjSrc {
+    const float* flow;      // [B,2,h,w], or UP: [B,2,hq,wq]
+    const float* depth;     // [B,1,h,w] (DEPTH only)
+    int64_t fb, fc, db;     // flow batch / channel stride, depth batch stride
+    int fh, dh;             // row strides
     int hq, wq;             // quarter-resolution size (UP only)
     float m0, m1;           // div_flow, time offset (UP only)
 };
@@ -134,82 +123,71 @@ __device__ __forceinline__ float up4_sample(const float* __restrict__ plane, int
                      plane[(int64_t)ty.i1 * hs + tx.i0], plane[(int64_t)ty.i1 * hs + tx.i1], ty, tx, m0, m1);
 }
 
-// A source pixel in two steps, so that a caller can have the loads of the next pixel in flight while
-// it works on the current one: proj_load only issues loads (raw values, no arithmetic on them),
-// proj_make turns them into the splat.
-struct ProjRaw {
-    bool in;                // inside the frame
-    int x, y;
-    float v[8];             // !UP: v[0] = fx, v[1] = fy;  UP: the 2 x 4 quarter-resolution taps
-    float d;                // depth weight (DEPTH only)
-};
+// A source pixel in two steps, so that a caller can have the loads of many pixels in flight before it
+// works on the first: pix_load only issues loads (raw values, no arithmetic on them), pix_flow turns
+// them into the pixel's flow.
+// Addressing is buffer-style: a wave-uniform descriptor per plane + a 32-bit byte offset split into a
+// per-lane part and a wave-uniform part (the row a wave works on advances on the scalar unit, at no
+// vector instruction per pixel); offsets past the plane read as 0.
+template <bool UP> struct ProjPix { float v[UP ? 8 : 2]; float d; };
+struct ProjPlanes { __amdgpu_buffer_rsrc_t f0, f1, d; };
 
 template <bool DEPTH, bool UP>
-__device__ __forceinline__ ProjRaw proj_load(const ProjFlow& f, const float* __restrict__ in2,
-                                             int b, int x, int y, int h, int w, vfi_strides s2) {
-    ProjRaw r;
-    r.in = x < w && y < h;
-    r.x = x; r.y = y;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r.v[k] = 0.0f;
-    r.d = 0.0f;
-    if (!r.in) return r;
-    if constexpr (UP) {
-        const UpTap ty = up4_tap(y, f.hq), tx = up4_tap(x, f.wq);
-        const float* q = f.p + (int64_t)b * f.s.b;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float* plane = q + (int64_t)c * f.s.c;
-            r.v[4 * c + 0] = plane[(int64_t)ty.i0 * f.s.h + tx.i0]; r.v[4 * c + 1] = plane[(int64_t)ty.i0 * f.s.h + tx.i1];
-            r.v[4 * c + 2] = plane[(int64_t)ty.i1 * f.s.h + tx.i0]; r.v[4 * c + 3] = plane[(int64_t)ty.i1 * f.s.h + tx.i1];
-        }
-    } else {
-        const float* flow = f.p + (int64_t)b * f.s.b + (int64_t)y * f.s.h + x;
-        r.v[0] = flow[0];
-        r.v[1] = flow[f.s.c];
-    }
-    if constexpr (DEPTH) r.d = in2[(int64_t)b * s2.b + (int64_t)y * s2.h + x];
-    return r;
+__device__ __forceinline__ ProjPlanes proj_planes(const ProjSrc& s, int b, int h, int w) {
+    const int rows = UP ? s.hq : h, cols = UP ? s.wq : w;
+    const float* f0 = s.flow + (int64_t)b * s.fb;
+    ProjPlanes p;
+    p.f0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ((rows - 1) * s.fh + cols) * 4, 0x00020000);
+    p.f1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + s.fc), 0, ((rows - 1) * s.fh + cols) * 4, 0x00020000);
+    p.d = p.f0;
+    if constexpr (DEPTH)
+        p.d = __builtin_amdgcn_make_buffer_rsrc((void*)(s.depth + (int64_t)b * s.db), 0, ((h - 1) * s.dh + w) * 4, 0x00020000);
+    return p;
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// pixel (x, yl + yu): x and yl may differ from lane to lane, yu is wave-uniform.  Inside the frame.
 template <bool DEPTH, bool UP>
-__device__ __forceinline__ ProjSplat proj_make(const ProjFlow& f, const ProjRaw& r, int h, int w) {
-    ProjSplat s;
-    s.valid = false;
-    s.L = s.T = s.R = s.Bm = 0;
-    s.ax = s.ay = s.ac = 0.0f;
-    if (!r.in) return s;
-    float fx, fy;
+__device__ __forceinline__ ProjPix<UP> pix_load(const ProjSrc& s, const ProjPlanes& p, int x, int yl, int yu) {
+    ProjPix<UP> r;
     if constexpr (UP) {
-        const UpTap ty = up4_tap(r.y, f.hq), tx = up4_tap(r.x, f.wq);
-        fx = up4_blend(r.v[0], r.v[1], r.v[2], r.v[3], ty, tx, f.m0, f.m1);
-        fy = up4_blend(r.v[4], r.v[5], r.v[6], r.v[7], ty, tx, f.m0, f.m1);
+        const UpTap ty = up4_tap(yl + yu, s.hq), tx = up4_tap(x, s.wq);
+        const int r0 = ty.i0 * s.fh, r1 = ty.i1 * s.fh;
+        r.v[0] = buf_f32(p.f0, (r0 + tx.i0) * 4, 0); r.v[1] = buf_f32(p.f0, (r0 + tx.i1) * 4, 0);
+        r.v[2] = buf_f32(p.f0, (r1 + tx.i0) * 4, 0); r.v[3] = buf_f32(p.f0, (r1 + tx.i1) * 4, 0);
+        r.v[4] = buf_f32(p.f1, (r0 + tx.i0) * 4, 0); r.v[5] = buf_f32(p.f1, (r0 + tx.i1) * 4, 0);
+        r.v[6] = buf_f32(p.f1, (r1 + tx.i0) * 4, 0); r.v[7] = buf_f32(p.f1, (r1 + tx.i1) * 4, 0);
+    } else {
+        const int vo = (yl * s.fh + x) * 4, so = yu * s.fh * 4;
+        r.v[0] = buf_f32(p.f0, vo, so);
+        r.v[1] = buf_f32(p.f1, vo, so);
+    }
+    r.d = 1.0f;
+    if constexpr (DEPTH) r.d = buf_f32(p.d, (yl * s.dh + x) * 4, yu * s.dh * 4);
+    return r;
+}
+template <bool UP>
+__device__ __forceinline__ void pix_flow(const ProjSrc& s, const ProjPix<UP>& r, int x, int y, float& fx, float& fy) {
+    if constexpr (UP) {
+        const UpTap ty = up4_tap(y, s.hq), tx = up4_tap(x, s.wq);
+        fx = up4_blend(r.v[0], r.v[1], r.v[2], r.v[3], ty, tx, s.m0, s.m1);
+        fy = up4_blend(r.v[4], r.v[5], r.v[6], r.v[7], ty, tx, s.m0, s.m1);
     } else {
         fx = r.v[0];
         fy = r.v[1];
     }
-    const float x2 = (float)r.x + fx;
-    const float y2 = (float)r.y + fy;
-    if (!(x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(w - 1) && y2 <= (float)(h - 1))) return s;
-    s.valid = true;
-    s.L = (int)x2;
-    s.T = (int)y2;
-    s.R = min(s.L + 1, w - 1);
-    s.Bm = min(s.T + 1, h - 1);
-    if constexpr (DEPTH) {
-        s.ax = -r.d * fx; s.ay = -r.d * fy; s.ac = r.d;     // depthflowprojection_cuda_kernel.cu:74-91
-    } else {
-        s.ax = -fx; s.ay = -fy; s.ac = 1.0f;                // flowprojection_cuda_kernel.cu:75-88
-    }
-    return s;
 }
-
-template <bool DEPTH, bool UP>
-__device__ __forceinline__ ProjSplat proj_source(const ProjFlow& f, const float* __restrict__ in2,
-                                                 int b, int x, int y, int h, int w, vfi_strides s2) {
-    return proj_make<DEPTH, UP>(f, proj_load<DEPTH, UP>(f, in2, b, x, y, h, w, s2), h, w);
+// The reference's test 0 <= x2 <= w - 1 (flowprojection_cuda_kernel.cu:69) as ONE unsigned comparison of
+// the float's bits with those of (float)(w - 1): non-negative floats order like their bit patterns, negative
+// ones (sign bit) and NaNs compare above every finite positive one.  (x2 = x + fx with x >= +0 is never -0.)
+__device__ __forceinline__ bool pix_target(float fx, float fy, int x, int y, unsigned wbits, unsigned hbits, int& L, int& T) {
+    const float x2 = (float)x + fx, y2 = (float)y + fy;
+    L = (int)x2;
+    T = (int)y2;
+    return (unsigned)__float_as_int(x2) <= wbits && (unsigned)__float_as_int(y2) <= hbits;
 }
-
 
 // min / max over each row of 16 lanes (four DPP row_shr steps); the result is in lane 15 of the row
 #define PROJ_ROW_STEP(OP, CTRL) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false))
@@ -223,79 +201,101 @@ __device__ __forceinline__ int row16_max(int v) {
 }
 #undef PROJ_ROW_STEP
 
-__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
-__device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
-__device__ __forceinline__ int hi16(int v) { return v >> 16; }
-
-// K0: displacement ranges per 16x16 block, target box per super-tile.  A wave covers 64 x 16 pixels (four
-// blocks side by side: lane = x, 16 rows in a loop), the 16 waves of a workgroup 4 x 4 of those.
+// K0: one wave per 64 x 16 pixels of the SOURCE frame (lane = x, 16 rows; all loads of the wave in flight at
+// once).  Per 16x16 block: the range of (L - x) and of (T - y) over its valid pixels; from it the output tiles the
+// block can reach, and for each of them the part of the block that can -- merged into that tile's source
+// rectangle with atomicMax (fields stored so that 0 means "nothing").
 template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(PROJ_SCAN_THREADS) void proj_scan(
-    ProjFlow flow, const float* __restrict__ in2, ProjGeom g, vfi_strides s2,
-    int* __restrict__ ws, float* __restrict__ planes, int64_t plane_floats) {
+__global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __restrict__ ws, float* __restrict__ planes,
+                                                int64_t plane_floats) {
     if (ws[PROJ_WS_DIRTY] != 0) {
         // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
         // a slice per workgroup (this call's K1 rewrites the word)
         const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
         const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
-        for (int64_t i = lo + threadIdx.x; i < hi; i += PROJ_SCAN_THREADS) planes[i] = 0.0f;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 64) planes[i] = 0.0f;
     }
-    __shared__ int sbox[4];
-    __shared__ int scost;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sup = blockIdx.x;
-    const int b = sup / g.nsup;
-    const int srem = sup - b * g.nsup;
-    const int sy = srem / g.sup_x, sx = srem - sy * g.sup_x;
-    if (tid < 4) sbox[tid] = tid < 2 ? INT_MAX : INT_MIN;
-    if (tid == 4) scost = 0;
-    __syncthreads();
-    const int x = sx * PROJ_SUP_W + (wave & 3) * 64 + lane;
-    const int y0 = sy * PROJ_SUP_H + (wave >> 2) * PROJ_BLK;
-    int dxmin = INT_MAX, dxmax = INT_MIN, dymin = INT_MAX, dymax = INT_MIN, vbits = 0, cbits = 0;
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile == 0 && lane == 0) ws[PROJ_WS_NLIST] = 0;      // K1 lists the tiles with holes for K2
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH;
+    const int xc = min(x, g.w - 1);
+    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
+    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
+    constexpr int GROUP = UP ? 4 : PROJ_TH;                 // rows whose loads are issued together
 #pragma unroll 1
-    for (int r0 = 0; r0 < PROJ_BLK; r0 += 4) {
-        ProjRaw raw[4];
+    for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
+        ProjPix<UP> raw[GROUP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) raw[k] = proj_load<DEPTH, UP>(flow, in2, b, x, y0 + r0 + k, g.h, g.w, s2);
+        for (int k = 0; k < GROUP; ++k) raw[k] = pix_load<DEPTH, UP>(src, pl, xc, 0, min(y0 + r0 + k, g.h - 1));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const ProjSplat s = proj_make<DEPTH, UP>(flow, raw[k], g.h, g.w);
-            if (s.valid) {
-                dxmin = min(dxmin, s.L - x); dxmax = max(dxmax, s.R - x);
-                dymin = min(dymin, s.T - raw[k].y); dymax = max(dymax, s.Bm - raw[k].y);
-                // non-negative floats order like their bit patterns
-                vbits = max(vbits, __float_as_int(fmaxf(fabsf(s.ax), fabsf(s.ay))));
-                cbits = max(cbits, __float_as_int(fabsf(s.ac)));
-            }
+        for (int k = 0; k < GROUP; ++k) {
+            const int y = y0 + r0 + k;
+            float fx, fy;
+            pix_flow<UP>(src, raw[k], xc, min(y, g.h - 1), fx, fy);
+            int L, T;
+            const bool valid = pix_target(fx, fy, x, y, wbits, hbits, L, T) && x < g.w && y < g.h;
+            const int dl = L - x, dt = T - y;
+            dlmin = min(dlmin, valid ? dl : INT_MAX); dlmax = max(dlmax, valid ? dl : INT_MIN);
+            dtmin = min(dtmin, valid ? dt : INT_MAX); dtmax = max(dtmax, valid ? dt : INT_MIN);
+            // the addends' magnitudes; non-negative floats order like their bit patterns
+            const float av = DEPTH ? fmaxf(fabsf(raw[k].d * fx), fabsf(raw[k].d * fy)) : fmaxf(fabsf(fx), fabsf(fy));
+            vbits = max(vbits, valid ? __float_as_int(av) : 0);
+            if constexpr (DEPTH) cbits = max(cbits, valid ? __float_as_int(fabsf(raw[k].d)) : 0);
+            else cbits = max(cbits, valid ? __float_as_int(1.0f) : 0);
         }
     }
-    dxmin = row16_min(dxmin); dxmax = row16_max(dxmax);
-    dymin = row16_min(dymin); dymax = row16_max(dymax);
+    dlmin = row16_min(dlmin); dlmax = row16_max(dlmax);
+    dtmin = row16_min(dtmin); dtmax = row16_max(dtmax);
     vbits = row16_max(vbits); cbits = row16_max(cbits);
-    if ((lane & 15) == 15) {
-        const bool any = dxmin != INT_MAX;
-        int4 e;
-        e.x = any ? pack16(dxmin, dxmax) : pack16(1, 0);
-        e.y = any ? pack16(dymin, dymax) : pack16(1, 0);
-        e.z = vbits;
-        e.w = cbits;
-        const int idx = (wave >> 2) * 16 + (wave & 3) * 4 + (lane >> 4);
-        reinterpret_cast<int4*>(ws + g.off_blk)[(int64_t)sup * PROJ_SUP_BLOCKS + idx] = e;
-        if (any) {
-            const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
-            const int X0 = max(bx0 + dxmin, 0), X1 = min(bx1 + dxmax, g.w - 1);
-            const int Y0 = max(y0 + dymin, 0), Y1 = min(by1 + dymax, g.h - 1);
-            atomicMin(&sbox[0], X0); atomicMin(&sbox[1], Y0);
-            atomicMax(&sbox[2], X1); atomicMax(&sbox[3], Y1);
-            atomicAdd(&scost, (X1 / PROJ_TW - X0 / PROJ_TW + 1) * (Y1 / PROJ_TH - Y0 / PROJ_TH + 1));
+    // The wave's four blocks sit side by side (lanes 15, 31, 47, 63 speak for them) and mostly feed the same two
+    // or three output tiles: per tile of the union of their ranges the four parts are merged in registers and the
+    // record is updated by ONE atomic instruction (lane k = field k) -- the atomics are the expensive part of
+    // this kernel (one wave instruction per ~50 ns per CU at the memory side, whatever its lane count).
+    const bool any = dlmin != INT_MAX;
+    const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
+    // top-left targets of the block lie in [X0, X1] x [Y0, Y1]; a target (L, T) feeds columns L, L + 1, rows T, T + 1
+    const int X0 = max(bx0 + dlmin, 0), X1 = min(bx1 + dlmax, g.w - 1);
+    const int Y0 = max(y0 + dtmin, 0), Y1 = min(by1 + dtmax, g.h - 1);
+    int ta = INT_MAX, tb = INT_MIN, tc = INT_MAX, td = INT_MIN;
+    bool wild = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sl = 16 * q + 15;
+        if (!__builtin_amdgcn_readlane((int)any, sl)) continue;
+        const int a0 = __builtin_amdgcn_readlane(X0, sl) / PROJ_TW, a1 = min(__builtin_amdgcn_readlane(X1, sl) + 1, g.w - 1) / PROJ_TW;
+        const int c0 = __builtin_amdgcn_readlane(Y0, sl) / PROJ_TH, c1 = min(__builtin_amdgcn_readlane(Y1, sl) + 1, g.h - 1) / PROJ_TH;
+        wild = wild || (a1 - a0 + 1) * (c1 - c0 + 1) > PROJ_BLOCK_CAP;
+        ta = min(ta, a0); tb = max(tb, a1); tc = min(tc, c0); td = max(td, c1);
+    }
+    if (wild) { if (lane == 0) ws[PROJ_WS_FLAG] = 1; return; }
+    for (int ty = tc; ty <= td; ++ty)
+        for (int tx = ta; tx <= tb; ++tx) {
+            const int ox0 = tx * PROJ_TW, oy0 = ty * PROJ_TH;
+            const int tx1 = min(ox0 + PROJ_TW - 1, g.w - 1), ty1 = min(oy0 + PROJ_TH - 1, g.h - 1);
+            // a pixel at x has L in [x + dlmin, x + dlmax]; the tile takes L in [ox0 - 1, tx1]
+            const int sx0 = max(bx0, ox0 - 1 - dlmax), sx1 = min(bx1, tx1 - dlmin);
+            const int sy0 = max(y0, oy0 - 1 - dtmax), sy1 = min(by1, ty1 - dtmin);
+            const bool hit = any && sx0 <= sx1 && sy0 <= sy1;
+            // fields as stored (0 = nothing), merged over the four blocks
+            int f0m = 0, f1m = 0, f2m = 0, f3m = 0, f4m = 0, f5m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sl = 16 * q + 15;
+                if (!__builtin_amdgcn_readlane((int)hit, sl)) continue;
+                f0m = max(f0m, 32767 - __builtin_amdgcn_readlane(sx0, sl)); f1m = max(f1m, 32767 - __builtin_amdgcn_readlane(sy0, sl));
+                f2m = max(f2m, __builtin_amdgcn_readlane(sx1, sl) + 1); f3m = max(f3m, __builtin_amdgcn_readlane(sy1, sl) + 1);
+                f4m = max(f4m, __builtin_amdgcn_readlane(vbits, sl)); f5m = max(f5m, __builtin_amdgcn_readlane(cbits, sl));
+            }
+            if (f2m == 0) continue;
+            int* e = ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS;
+            const int v = lane == 0 ? f0m : lane == 1 ? f1m : lane == 2 ? f2m : lane == 3 ? f3m : lane == 4 ? f4m : f5m;
+            if (lane < 6) atomicMax(&e[lane], v);
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        reinterpret_cast<int4*>(ws + g.off_sup)[sup] = make_int4(sbox[0], sbox[1], sbox[2], sbox[3]);
-        if (scost) atomicAdd(reinterpret_cast<unsigned long long*>(ws + PROJ_WS_COST), (unsigned long long)scost);
-    }
 }
 
 // the two halves of a packed sum, exactly: S = hi * 2^32 + lo with both in int32
@@ -310,205 +310,266 @@ __device__ __forceinline__ int packed_hi(unsigned long long s) {
 template <bool DEPTH> struct ProjCountCell { typedef unsigned type; };
 template <> struct ProjCountCell<true> { typedef unsigned long long type; };    // (addends << 32) + scaled weight sum
 
-// K1: one workgroup per output tile
+// K1: one workgroup per output tile.  Each source pixel of the tile's rectangle adds its addend ONCE, at its
+// top-left target, into a (16 + 1) x (64 + 1) grid (one row above and one column left of the tile included);
+// a cell of the tile is then the sum of the 2 x 2 grid cells whose splats cover it (integer sums: exact, so
+// this equals adding every addend to its four targets).  At the last column / row of the frame R == L / B == T:
+// the reference adds twice there (flowprojection_cuda_kernel.cu:72-73), so does the sum below.
+//
+// Workgroup size: the kernel is bound by instruction issue, not by memory, and every tile costs the same, so
+// what matters is that ALL tiles are resident at once (a 1080p frame has 2232 tiles; 8 workgroups of 256
+// threads per CU would hold 2048 and leave a second round that doubles the time).  128 threads per tile:
+// up to 9 workgroups per CU within the LDS, 8 output cells and ~11 source pixels per thread.
+#ifndef PROJ_PULL_THREADS
+#define PROJ_PULL_THREADS 128
+#endif
+#ifndef PROJ_PULL_WAVES
+#define PROJ_PULL_WAVES 5           // 9 workgroups x 2 waves per CU
+#endif
+#ifndef PROJ_PULL_CH
+#define PROJ_PULL_CH 5              // source pixels whose loads a thread has in flight
+#endif
+#define PROJ_AW (PROJ_TW + 1)
+#define PROJ_AH (PROJ_TH + 1)
+#define PROJ_CELLS (PROJ_AH * PROJ_AW)
+#define PROJ_NW (PROJ_PULL_THREADS / 64)            // waves per workgroup
+#define PROJ_ROWS (PROJ_TH / PROJ_NW)               // consecutive tile rows per wave in the epilogue
+#define PROJ_ACCC_OFF ((PROJ_CELLS * 8 + 15) & ~15)
+template <bool DEPTH> struct ProjLds {
+    static constexpr int acc_bytes = (PROJ_ACCC_OFF + PROJ_CELLS * (DEPTH ? 8 : 4) + 15) & ~15;
+    static constexpr int total = acc_bytes + PROJ_TW * 4 + 16;     // + column masks + two counters
+};
+
 template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(PROJ_THREADS, 8) void proj_pull(
-    ProjFlow flow, const float* __restrict__ in2, float* __restrict__ count, float* __restrict__ out,
-    ProjGeom g, vfi_strides s1, vfi_strides s2, vfi_strides sc, int* __restrict__ ws, int* __restrict__ bits,
-    float* __restrict__ planes, unsigned long long cost_limit) {
+__global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
+    ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
+    int64_t cb, int ch, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes) {
     typedef typename ProjCountCell<DEPTH>::type ccell;
-    __shared__ unsigned long long accv[PROJ_TH][PROJ_TW];
-    __shared__ ccell accc[PROJ_TH][PROJ_TW];
-    __shared__ int s_hits[PROJ_MAXHIT];
-    __shared__ int s_st[8];             // 0 hits, 1..4 box x0 y0 x1 y1, 5 / 6 bits of the largest addends, 7 most addends in a cell
-    __shared__ unsigned s_colm[PROJ_TW];
-    __shared__ int s_holes;
+    __shared__ uint4 lds[ProjLds<DEPTH>::total / 16];
+    unsigned long long* accv = reinterpret_cast<unsigned long long*>(lds);
+    ccell* accc = reinterpret_cast<ccell*>(reinterpret_cast<char*>(lds) + PROJ_ACCC_OFF);
+    unsigned* s_colm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::acc_bytes);
+    int* s_misc = reinterpret_cast<int*>(s_colm + PROJ_TW);        // [0] most addends in a cell, [1] holes, [2] negative counts
     const int tile = blockIdx.x;
     const int per_img = g.tiles_x * g.tiles_y;
     const int b = tile / per_img;
     const int trem = tile - b * per_img;
     const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (provably wave-uniform: scalar row offsets)
     const int ox0 = txi * PROJ_TW, oy0 = tyi * PROJ_TH;
-    const bool fallback = *reinterpret_cast<const unsigned long long*>(ws + PROJ_WS_COST) > cost_limit;
+    const bool fallback = ws[PROJ_WS_FLAG] != 0;
+#ifdef PROJ_STAMPS          // development build only: when and where each workgroup ran (tools/proj_stamps.py)
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_t1 = 0, st_t2 = 0;
+#endif
     if (tile == 0 && tid == 0) ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;
+    int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
+    const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5];
+    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
+    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
 
     if (fallback) {
+        __syncthreads();
+        if (tid < 6) entry[tid] = 0;
         // the reference's own scheme: this tile as SOURCE tile, global atomics into the dense scratch
         // planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
         const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
         float* o0 = planes + (int64_t)b * g.h * g.w;
         float* o1 = o0 + npx;
         float* cn = o1 + npx;
-#pragma unroll
-        for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const ProjSplat s = proj_source<DEPTH, UP>(flow, in2, b, ox0 + lane, oy0 + wave + r * 4, g.h, g.w, s2);
-            if (!s.valid) continue;
-            const int64_t oT = (int64_t)s.T * g.w, oB = (int64_t)s.Bm * g.w;
-            atomicAdd(&o0[oT + s.L], s.ax); atomicAdd(&o0[oT + s.R], s.ax); atomicAdd(&o0[oB + s.L], s.ax); atomicAdd(&o0[oB + s.R], s.ax);
-            atomicAdd(&o1[oT + s.L], s.ay); atomicAdd(&o1[oT + s.R], s.ay); atomicAdd(&o1[oB + s.L], s.ay); atomicAdd(&o1[oB + s.R], s.ay);
-            atomicAdd(&cn[oT + s.L], s.ac); atomicAdd(&cn[oT + s.R], s.ac); atomicAdd(&cn[oB + s.L], s.ac); atomicAdd(&cn[oB + s.R], s.ac);
+        const int x = ox0 + lane;
+        for (int r = 0; r < PROJ_ROWS; ++r) {
+            const int y = oy0 + wave * PROJ_ROWS + r;
+            if (x >= g.w || y >= g.h) continue;
+            float fx, fy;
+            const ProjPix<UP> p = pix_load<DEPTH, UP>(src, pl, x, 0, y);
+            pix_flow<UP>(src, p, x, y, fx, fy);
+            int L, T;
+            if (!pix_target(fx, fy, x, y, wbits, hbits, L, T)) continue;
+            const int R = min(L + 1, g.w - 1), Bm = min(T + 1, g.h - 1);
+            const float ax = DEPTH ? -p.d * fx : -fx, ay = DEPTH ? -p.d * fy : -fy, ac = p.d;   // (:75-88; depth :74-91)
+            const int64_t oT = (int64_t)T * g.w, oB = (int64_t)Bm * g.w;
+            atomicAdd(&o0[oT + L], ax); atomicAdd(&o0[oT + R], ax); atomicAdd(&o0[oB + L], ax); atomicAdd(&o0[oB + R], ax);
+            atomicAdd(&o1[oT + L], ay); atomicAdd(&o1[oT + R], ay); atomicAdd(&o1[oB + L], ay); atomicAdd(&o1[oB + R], ay);
+            atomicAdd(&cn[oT + L], ac); atomicAdd(&cn[oT + R], ac); atomicAdd(&cn[oB + L], ac); atomicAdd(&cn[oB + R], ac);
         }
         return;
     }
 
-    if (tid < 8) s_st[tid] = (tid == 1 || tid == 2) ? INT_MAX : (tid == 3 || tid == 4) ? INT_MIN : 0;
-    if (tid < PROJ_TW) s_colm[tid] = 0u;
-    if (tid == 8) s_holes = 0;
-    for (int i = tid; i < PROJ_TH * PROJ_TW; i += PROJ_THREADS) { (&accv[0][0])[i] = 0ull; (&accc[0][0])[i] = 0; }
+    for (int i = tid; i < ProjLds<DEPTH>::total / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
+    if (tid < 6) entry[tid] = 0;                            // every thread has read the record: empty for the next call
 
-    // ---- which pixels can reach this tile
-    const int tx1 = min(ox0 + PROJ_TW - 1, g.w - 1), ty1 = min(oy0 + PROJ_TH - 1, g.h - 1);
-    const int4* supt = reinterpret_cast<const int4*>(ws + g.off_sup) + (int64_t)b * g.nsup;
-    for (int s = tid; s < g.nsup; s += PROJ_THREADS) {
-        const int4 e = supt[s];
-        if (e.x <= tx1 && e.z >= ox0 && e.y <= ty1 && e.w >= oy0) {
-            const int k = atomicAdd(&s_st[0], 1);
-            if (k < PROJ_MAXHIT) s_hits[k] = s;
-        }
-    }
-    __syncthreads();
-    {
-        const int nhit = s_st[0];
-        const bool all = nhit > PROJ_MAXHIT;                // (then every super-tile is scanned: a superset)
-        const int nscan = all ? g.nsup : nhit;
-        const int4* blkt = reinterpret_cast<const int4*>(ws + g.off_blk) + (int64_t)b * g.nsup * PROJ_SUP_BLOCKS;
-        for (int k = wave; k < nscan; k += PROJ_THREADS / 64) {
-            const int s = all ? k : s_hits[k];
-            const int4 e = blkt[(int64_t)s * PROJ_SUP_BLOCKS + lane];
-            const int ssy = s / g.sup_x, ssx = s - ssy * g.sup_x;
-            const int bx0 = ssx * PROJ_SUP_W + (lane & 15) * PROJ_BLK, by0 = ssy * PROJ_SUP_H + (lane >> 4) * PROJ_BLK;
-            const int bx1 = min(bx0 + PROJ_BLK - 1, g.w - 1), by1 = min(by0 + PROJ_BLK - 1, g.h - 1);
-            const int dxmin = lo16(e.x), dxmax = hi16(e.x), dymin = lo16(e.y), dymax = hi16(e.y);
-            // a pixel at x reaches columns [x + dxmin, x + dxmax] at most
-            const int sx0 = max(bx0, ox0 - dxmax), sx1 = min(bx1, tx1 - dxmin);
-            const int sy0 = max(by0, oy0 - dymax), sy1 = min(by1, ty1 - dymin);
-            if (dxmin <= dxmax && sx0 <= sx1 && sy0 <= sy1) {
-                atomicMin(&s_st[1], sx0); atomicMin(&s_st[2], sy0);
-                atomicMax(&s_st[3], sx1); atomicMax(&s_st[4], sy1);
-                atomicMax(&s_st[5], e.z); atomicMax(&s_st[6], e.w);
-            }
-        }
-    }
-    __syncthreads();
-    const int ux0 = s_st[1], uy0 = s_st[2];
-    const int uw = s_st[3] - ux0 + 1, uh = s_st[3] >= ux0 ? s_st[4] - uy0 + 1 : 0;   // uh == 0: nothing lands here
+    const int ux0 = 32767 - e0, uy0 = 32767 - e1;
+    const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
     // fixed-point scales: every addend that reaches this tile is below 2^e with e from the blocks' maxima, so
     // addend * 2^(25 - e) is below 2^25 in magnitude
     int ev = 0, ec = 0;
-    (void)frexpf(__int_as_float(s_st[5]), &ev);
-    (void)frexpf(__int_as_float(s_st[6]), &ec);
+    (void)frexpf(__int_as_float(e4), &ev);
+    (void)frexpf(__int_as_float(e5), &ec);
     // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
     int kv = max(-100, min(100, PROJ_ADD_BITS - ev)), kc = max(-100, min(100, PROJ_ADD_BITS - ec));
 
+    const int x = ox0 + lane;
+    const bool xlast = x == g.w - 1;                        // R == L there: the column adds twice
+    const int yl0 = wave * PROJ_ROWS;
+    unsigned long long sumv[PROJ_ROWS];
+    ccell sumc[PROJ_ROWS];
     for (int attempt = 0;; ++attempt) {
-        const float sv = ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);     // exact powers of two
-        if (uh > 0) {
-            // thread i takes pixels i, i + 256, ... of U in row-major order (lanes = consecutive x); the next
-            // pixel's loads are in flight while the current one is accumulated
-            const int stepx = PROJ_THREADS % uw, stepy = PROJ_THREADS / uw;
-            int yi = tid / uw, xi = tid - yi * uw;
-            ProjRaw nxt = proj_load<DEPTH, UP>(flow, in2, b, ux0 + xi, yi < uh ? uy0 + yi : g.h, g.h, g.w, s2);
-            while (yi < uh) {
-                const ProjRaw cur = nxt;
-                xi += stepx; yi += stepy;
-                if (xi >= uw) { xi -= uw; yi += 1; }
-                nxt = proj_load<DEPTH, UP>(flow, in2, b, ux0 + xi, yi < uh ? uy0 + yi : g.h, g.h, g.w, s2);
-                const ProjSplat s = proj_make<DEPTH, UP>(flow, cur, g.h, g.w);
-                // cells of this output tile only; R == L / Bm == T at the far edges add twice (:72-73)
-                const int lx = s.L - ox0, rx = s.R - ox0, ty = s.T - oy0, by = s.Bm - oy0;
-                const bool inL = s.valid && (unsigned)lx < PROJ_TW, inR = s.valid && (unsigned)rx < PROJ_TW;
-                const bool inT = (unsigned)ty < PROJ_TH, inB = (unsigned)by < PROJ_TH;
-                // addend * 2^k is exact in float (power-of-two scale)
-                const unsigned long long qv = pack2(__float2int_rn(s.ax * sv), __float2int_rn(s.ay * sv));
-                ccell qc;
-                if constexpr (DEPTH) qc = pack2(1, __float2int_rn(s.ac * scn)); else qc = 1u;
-                if (inT && inL) { atomicAdd(&accv[ty][lx], qv); atomicAdd(&accc[ty][lx], qc); }
-                if (inT && inR) { atomicAdd(&accv[ty][rx], qv); atomicAdd(&accc[ty][rx], qc); }
-                if (inB && inL) { atomicAdd(&accv[by][lx], qv); atomicAdd(&accc[by][lx], qc); }
-                if (inB && inR) { atomicAdd(&accv[by][rx], qv); atomicAdd(&accc[by][rx], qc); }
+        const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
+        // The rectangle is walked in strips of up to 64 columns.  A full strip: lane = column, the workgroup's
+        // waves take its rows in turn (row base and flow row pointer advance on the scalar unit: no per-pixel
+        // index arithmetic).  The last, narrower strip packs 64 / width rows into a wave the same way.  CH
+        // pixels' loads are in flight per lane.
+        constexpr int CH = UP ? 2 : PROJ_PULL_CH;
+        for (int cs = 0; cs < uw && uh > 0; cs += 64) {
+            const int width = min(64, uw - cs), rpi = 64 / width;      // rows per wave instruction
+            const int lr = lane / width, lc = lane - lr * width;
+            const int px = ux0 + cs + lc;
+            const bool lane_on = lr < rpi;                              // (rows past the rectangle are loaded -- past the plane
+                                                                        //  they read as 0 -- and ignored)
+            const int step = PROJ_NW * rpi;
+            for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
+                ProjPix<UP> raw[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                    for (int q = 0; q < (UP ? 8 : 2); ++q) raw[k].v[q] = 0.0f;
+                    raw[k].d = 0.0f;
+                    if (row0 + k * step < uh) raw[k] = pix_load<DEPTH, UP>(src, pl, px, lr, uy0 + row0 + k * step);   // (wave-uniform test)
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int rowk = row0 + k * step + lr;
+                    const int py = uy0 + rowk;
+                    float fx, fy;
+                    pix_flow<UP>(src, raw[k], px, py, fx, fy);
+                    int L, T;
+                    const bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
+                    const unsigned c = (unsigned)(L - (ox0 - 1)), r = (unsigned)(T - (oy0 - 1));
+                    if (valid && lane_on && rowk < uh && c < PROJ_AW && r < PROJ_AH) {
+                        const int idx = r * PROJ_AW + c;
+                        // addend * 2^k is exact in float (power-of-two scale)
+                        const float ax = DEPTH ? raw[k].d * fx : fx, ay = DEPTH ? raw[k].d * fy : fy;   // (:75-88; depth :74-91)
+                        atomicAdd(&accv[idx], pack2(__float2int_rn(ax * sv), __float2int_rn(ay * sv)));
+                        if constexpr (DEPTH) atomicAdd(&accc[idx], pack2(1, __float2int_rn(raw[k].d * scn)));
+                        else atomicAdd(&accc[idx], 1u);
+                    }
+                }
             }
         }
+#ifdef PROJ_STAMPS
+        if (!attempt) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+        // a cell = the grid cells of the top-left targets (x, y), (x - 1, y), (x, y - 1), (x - 1, y - 1): per grid
+        // row the horizontal pair once, shared by the two tile rows it feeds
+        int nmax = 0;
+        const unsigned long long xm = xlast ? ~0ull : 0ull;
+        const ccell xmc = xlast ? (ccell)~(ccell)0 : (ccell)0;
+        const int i0 = yl0 * PROJ_AW + lane;
+        unsigned long long hv = accv[i0] + accv[i0 + 1] + (accv[i0 + 1] & xm);
+        ccell hc = accc[i0] + accc[i0 + 1] + (accc[i0 + 1] & xmc);
+#pragma unroll
+        for (int r = 0; r < PROJ_ROWS; ++r) {
+            const int i1 = i0 + (r + 1) * PROJ_AW;
+            unsigned long long hv1 = accv[i1] + accv[i1 + 1] + (accv[i1 + 1] & xm);
+            ccell hc1 = accc[i1] + accc[i1 + 1] + (accc[i1 + 1] & xmc);
+            unsigned long long v = hv + hv1;
+            ccell c = hc + hc1;
+            if (oy0 + yl0 + r == g.h - 1) { v += hv1; c += hc1; }      // B == T there: the row adds twice
+            sumv[r] = v; sumc[r] = c;
+            hv = hv1; hc = hc1;
+            if (x < g.w && oy0 + yl0 + r < g.h) {
+                if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, (ccell)0x7fffffffu));
+            }
+        }
         if (attempt) break;
         // did every cell stay within the addends its 32-bit halves can hold?
-        int nmax = 0;
-#pragma unroll
-        for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const ccell c = accc[wave + r * 4][lane];
-            if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, 0x7fffffffu));
-        }
         nmax = wave_max_i32(nmax);
-        if (lane == 0 && nmax > PROJ_ADD_CELL) atomicMax(&s_st[7], nmax);
+        if (lane == 0 && nmax > PROJ_ADD_CELL) atomicMax(&s_misc[0], nmax);
         __syncthreads();
-        nmax = s_st[7];
+        nmax = s_misc[0];
         if (nmax <= PROJ_ADD_CELL) break;
         // once more with addends small enough for the busiest cell
         const int shift = (32 - __clz(nmax - 1)) - 5;           // ceil(log2(nmax)) - log2(32)
         kv -= shift; kc -= shift;
-        for (int i = tid; i < PROJ_TH * PROJ_TW; i += PROJ_THREADS) { (&accv[0][0])[i] = 0ull; (&accc[0][0])[i] = 0; }
+        for (int i = tid; i < ProjLds<DEPTH>::acc_bytes / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
 
+#ifdef PROJ_STAMPS
+    st_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once; leave the two
-    // "count != 0" bitmaps and the number of holes for the hole filler
-    const int x = ox0 + lane;
-    float cv[PROJ_TH / 4], vxv[PROJ_TH / 4], vyv[PROJ_TH / 4];
+    // "count != 0" bitmaps for the hole filler and put the tile on its list if it has holes
     unsigned mine = 0u;
-    int holes = 0;
+    int holes = 0, negs = 0;
+    float* o = out + (int64_t)b * ob + (unsigned)((oy0 + yl0) * oh + x);
+    float* cnp = count + (int64_t)b * cb + (unsigned)((oy0 + yl0) * ch + x);
 #pragma unroll
-    for (int r = 0; r < PROJ_TH / 4; ++r) {
-        const int yl = wave + r * 4;
-        const bool inside = x < g.w && oy0 + yl < g.h;
+    for (int r = 0; r < PROJ_ROWS; ++r) {
+        const int yl = yl0 + r, y = oy0 + yl;
+        const bool inside = x < g.w && y < g.h;
         // exact integer sums -> float once
-        const unsigned long long sv2 = accv[yl][lane];
-        const ccell cc = accc[yl][lane];
         float c;
-        if constexpr (DEPTH) c = ldexpf((float)packed_lo(cc), -kc); else c = (float)cc;
-        float vx = ldexpf((float)packed_hi(sv2), -kv), vy = ldexpf((float)packed_lo(sv2), -kv);
+        if constexpr (DEPTH) c = ldexpf((float)packed_lo(sumc[r]), -kc); else c = (float)sumc[r];
+        float vx = ldexpf((float)packed_hi(sumv[r]), -kv), vy = ldexpf((float)packed_lo(sumv[r]), -kv);
         if (c > 0.0f) { vx /= c; vy /= c; }
-        cv[r] = c; vxv[r] = vx; vyv[r] = vy;
         const bool nz = inside && c != 0.0f;
         const unsigned long long rowbits = __ballot(nz);
-        if (lane < 2 && oy0 + yl < g.h && txi * 2 + lane < g.rmw)
-            bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
+        if (lane < 2 && y < g.h && txi * 2 + lane < g.rmw)
+            bits[g.rowmap + (b * g.h + y) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
         if (nz) mine |= 1u << yl;
         holes += __popcll(__ballot(inside && c <= 0.0f));
-    }
-    if (mine) atomicOr(&s_colm[lane], mine);
-    if (lane == 0 && holes) atomicAdd(&s_holes, holes);
-    __syncthreads();
-    // a column word holds two tiles' rows: each tile stores its own 16-bit half
-    if (tid < PROJ_TW && ox0 + tid < g.w)
-    {
-        unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + tid) * g.cmw) * 2;
-        half[tyi] = (unsigned short)s_colm[tid];
-        if (tyi == g.tiles_y - 1 && (tyi & 1) == 0) half[tyi + 1] = 0;     // the unused half of the last word
-    }
-    if (tid == 0) ws[g.off_holes + tile] = s_holes;
-    if (x < g.w) {
-#pragma unroll
-        for (int r = 0; r < PROJ_TH / 4; ++r) {
-            const int y = oy0 + wave + r * 4;
-            if (y >= g.h) continue;
-            float* o = out + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
-            o[0] = vxv[r];
-            o[s1.c] = vyv[r];
-            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = cv[r];
+        if constexpr (DEPTH) negs += __popcll(__ballot(inside && c < 0.0f));
+        if (inside) {
+            o[(unsigned)(r * oh)] = vx;
+            o[oc + (unsigned)(r * oh)] = vy;
+            cnp[(unsigned)(r * ch)] = c;
         }
     }
+    if (mine) atomicOr(&s_colm[lane], mine);
+    if (lane == 0 && holes) atomicAdd(&s_misc[1], holes);
+    if (lane == 0 && negs) atomicAdd(&s_misc[2], negs);
+    __syncthreads();
+    // a column word holds two tiles' rows: each tile stores its own 16-bit half (and the unused halves that
+    // pad a column line to whole 16-byte groups, if it is the last tile of the column)
+    if (tid < PROJ_TW && ox0 + tid < g.w) {
+        unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + tid) * g.cmw) * 2;
+        half[tyi] = (unsigned short)s_colm[tid];
+        if (tyi == g.tiles_y - 1)
+            for (int k = tyi + 1; k < 2 * g.cmw; ++k) half[k] = 0;
+    }
+    // the list entry: the tile, flagged when it holds negative counts (non-zero, yet holes: K2 then reads the counts)
+    if (tid == 0 && s_misc[1]) ws[g.off_list + atomicAdd(&ws[PROJ_WS_NLIST], 1)] = tile | (s_misc[2] ? (int)0x80000000 : 0);
+#ifdef PROJ_STAMPS
+    if (tid == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + g.off_list + g.ntiles + (g.ntiles & 1)) + (int64_t)tile * 8;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st[0] = st_t0; st[1] = st_t1; st[2] = st_t2; st[3] = __builtin_amdgcn_s_memtime();
+        st[4] = st_r0; st[5] = __builtin_amdgcn_s_memrealtime(); st[6] = hwid; st[7] = xcc;
+    }
+#endif
 }
 
 // K2: pass 3 (flowprojection_cuda_kernel.cu:175-231).  A cell read here is either a non-hole
 // (never written by this pass) or is multiplied by 0.
 //
 // The reference walks cell by cell from every hole until it meets a non-zero count; along an
-// uncovered border strip that is a dependent chain of up to H (or W) loads per hole.  On the
-// normal path K1 has left row-packed and column-packed bitmaps of "count != 0", so a walk is a
-// few word loads and a count-leading/trailing-zeros; only the cell found is then read.  The cell
-// found -- hence the result -- is the same.  Tiles without holes (K1 counted them) leave at once.
+// uncovered border strip that is a dependent chain of up to H (or W) loads per hole.  K1 has left
+// row-packed and column-packed bitmaps of "count != 0" and a list of the tiles that have holes.  A
+// workgroup takes a listed tile, one thread per cell.  Along the row: the wave of a row loads the row's
+// whole bitmap line at once (lane i = word i) and every lane finds its neighbours from registers (a
+// ballot says which words are non-zero, a lane exchange fetches the word).  Along the column: a lane
+// loads its own word and the two beside it, and the whole line once to learn which words are non-zero
+// (a neighbour further than a word away, rare, costs one more load).  Two dependent rounds of loads per
+// hole -- lines, then the four cells found -- whatever the distance.  The cell found, hence the result,
+// is the reference's.
 struct ProjScan { int pos; float cnt; };
 
 // cell-by-cell walk of the reference (fallback path: no bitmaps)
@@ -519,28 +580,58 @@ __device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn
     return r;
 }
 
-__global__ __launch_bounds__(PROJ_THREADS) void proj_finish(
+#define PROJ_FIN_THREADS 1024
+#define PROJ_LINE_CHUNKS 2          // bitmap lines of up to 128 words (4096 pixels) are searched in registers
+
+// nearest non-zero word strictly below / above word j of a line whose non-zero words are flagged in m[]; -1: none
+__device__ __forceinline__ int mask_prev(const unsigned long long* m, int j) {
+    int found = -1;
+#pragma unroll
+    for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) {
+        const int rel = j - 64 * c;                                 // words of this chunk below j: bits < rel
+        const unsigned long long q = rel <= 0 ? 0ull : rel >= 64 ? m[c] : (m[c] & ((1ull << rel) - 1ull));
+        if (q) found = 64 * c + 63 - __clzll((long long)q);
+    }
+    return found;
+}
+__device__ __forceinline__ int mask_next(const unsigned long long* m, int j) {
+    int found = -1;
+#pragma unroll
+    for (int c = PROJ_LINE_CHUNKS - 1; c >= 0; --c) {
+        const int rel = j - 64 * c;                                 // words of this chunk above j: bits > rel
+        const unsigned long long q = rel >= 63 ? 0ull : rel < 0 ? m[c] : (m[c] & ~((2ull << rel) - 1ull));
+        if (q) found = 64 * c + __ffsll((long long)q) - 1;
+    }
+    return found;
+}
+
+__global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
     int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
-    const int tile = blockIdx.x;
+    // (the three words are loaded together: the list entry is read before the list's length is known)
     const bool fallback = ws[PROJ_WS_DIRTY] != 0;
-    if (tile == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(ws + PROJ_WS_COST) = 0ull;   // K0 of the next call sums from 0
-    if (!fallback && (!fillhole || ws[g.off_holes + tile] == 0)) return;
+    const int nlist = ws[PROJ_WS_NLIST];
+    int entry = ws[g.off_list + (blockIdx.x < (unsigned)g.ntiles ? blockIdx.x : 0)];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;         // K0 of the next call starts afresh
+    if (!fallback && !fillhole) return;
     const int per_img = g.tiles_x * g.tiles_y;
-    const int b = tile / per_img;
-    const int trem = tile - b * per_img;
-    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = txi * PROJ_TW + lane;
-    if (x >= g.w) return;
-    float* o0 = out + (int64_t)b * s1.b;
-    float* o1 = o0 + s1.c;
-#pragma unroll 1
-    for (int r = 0; r < PROJ_TH / 4; ++r) {
-        const int y = tyi * PROJ_TH + wave + r * 4;
-        if (y >= g.h) continue;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;            // wave = row of the tile
+    const int nwork = fallback ? g.ntiles : nlist;
+    const bool generic = g.rmw > 64 * PROJ_LINE_CHUNKS || g.cmw > 64 * PROJ_LINE_CHUNKS;
+    for (int item = blockIdx.x; item < nwork; item += gridDim.x) {
+        if (item != (int)blockIdx.x) entry = ws[g.off_list + item];
+        const int tile = fallback ? item : (entry & 0x7fffffff);
+        const bool negatives = entry < 0;
+        const int b = tile / per_img;
+        const int trem = tile - b * per_img;
+        const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+        const int x = txi * PROJ_TW + lane, y = tyi * PROJ_TH + wave;
+        const bool inside = x < g.w && y < g.h;
+        float* o0 = out + (int64_t)b * s1.b;
+        float* o1 = o0 + s1.c;
         const int64_t row = (int64_t)y * s1.h;
         if (fallback) {
+            if (!inside) continue;
             // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
             const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
             const float* p0 = planes + (int64_t)b * g.h * g.w;
@@ -578,12 +669,64 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_finish(
             continue;
         }
         const float* cn = count + (int64_t)b * sc.b;
-        if (!(cn[(int64_t)y * sc.h + x] <= 0.0f)) continue;
-        // K1 ran its normal path and left the bitmaps
-        const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
-        const int* cl = bits + g.colmap + (b * g.w + x) * g.cmw;
-        const int xl = proj_bit_walk(rl, x, g.w, -1), xr = proj_bit_walk(rl, x, g.w, +1);
-        const int yu = proj_bit_walk(cl, y, g.h, -1), yd = proj_bit_walk(cl, y, g.h, +1);
+        const int* rl = bits + g.rowmap + (b * g.h + min(y, g.h - 1)) * g.rmw;
+        const int* cl = bits + g.colmap + (b * g.w + min(x, g.w - 1)) * g.cmw;
+        int xl, xr, yu, yd;
+        if (generic) {
+            if (!(inside && cn[(int64_t)y * sc.h + x] <= 0.0f)) continue;
+            xl = proj_bit_walk(rl, x, g.w, -1); xr = proj_bit_walk(rl, x, g.w, +1);
+            yu = proj_bit_walk(cl, y, g.h, -1); yd = proj_bit_walk(cl, y, g.h, +1);
+        } else {
+            // ---- one round of loads: the row's line (lane i = word 64 c + i), this lane's column line (16-byte
+            //      loads, reduced to "which words are non-zero") and its own column word with the two beside it
+            unsigned rw[PROJ_LINE_CHUNKS];
+            unsigned long long rm[PROJ_LINE_CHUNKS], cm[PROJ_LINE_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rw[c] = (64 * c + lane < g.rmw) ? (unsigned)rl[64 * c + lane] : 0u;
+            const int i = y >> 5, ib = y & 31, cwords = g.cmw;
+            const unsigned cown = (unsigned)cl[i], cprev = i > 0 ? (unsigned)cl[i - 1] : 0u, cnext = i + 1 < cwords ? (unsigned)cl[i + 1] : 0u;
+            const float cme = (negatives && inside) ? cn[(int64_t)y * sc.h + x] : 0.0f;
+            {
+                const int4* cl4 = reinterpret_cast<const int4*>(cl);
+                const int groups = cwords / 4;
+#pragma unroll
+                for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) {
+                    unsigned long long m = 0ull;
+#pragma unroll 4
+                    for (int k = 16 * c; k < min(groups, 16 * c + 16); ++k) {
+                        const int4 q = cl4[k];
+                        const unsigned long long nib = (q.x ? 1ull : 0ull) | (q.y ? 2ull : 0ull) | (q.z ? 4ull : 0ull) | (q.w ? 8ull : 0ull);
+                        m |= nib << ((4 * k) & 63);
+                    }
+                    cm[c] = m;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rm[c] = __ballot(rw[c] != 0u);
+            const int j = x >> 5, jb = x & 31;
+            const int jl = mask_prev(rm, j), jr = mask_next(rm, j);
+            // the words themselves come from the lanes that hold them
+            unsigned own = 0u, wl = 0u, wr = 0u;
+#pragma unroll
+            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) {
+                const unsigned a = (unsigned)__shfl((int)rw[c], j & 63), l2 = (unsigned)__shfl((int)rw[c], jl & 63), r2 = (unsigned)__shfl((int)rw[c], jr & 63);
+                if ((j >> 6) == c) own = a;
+                if (jl >= 0 && (jl >> 6) == c) wl = l2;
+                if (jr >= 0 && (jr >> 6) == c) wr = r2;
+            }
+            // a hole: its bit is clear -- or, in a tile that holds negative counts, its count is not positive
+            const bool hole = inside && (negatives ? cme <= 0.0f : ((own >> jb) & 1u) == 0u);
+            if (!hole) continue;
+            const unsigned below = own & ((1u << jb) - 1u), above = jb == 31 ? 0u : own & ~((2u << jb) - 1u);
+            xl = below ? j * 32 + 31 - __clz(below) : jl >= 0 ? jl * 32 + 31 - __clz(wl) : -1;
+            xr = above ? j * 32 + __ffs((int)above) - 1 : jr >= 0 ? jr * 32 + __ffs((int)wr) - 1 : -1;
+            const int iu = mask_prev(cm, i), id = mask_next(cm, i);
+            const unsigned cu = iu < 0 ? 0u : iu == i - 1 ? cprev : (unsigned)cl[iu];
+            const unsigned cd = id < 0 ? 0u : id == i + 1 ? cnext : (unsigned)cl[id];
+            const unsigned cbelow = cown & ((1u << ib) - 1u), cabove = ib == 31 ? 0u : cown & ~((2u << ib) - 1u);
+            yu = cbelow ? i * 32 + 31 - __clz(cbelow) : iu >= 0 ? iu * 32 + 31 - __clz(cu) : -1;
+            yd = cabove ? i * 32 + __ffs((int)cabove) - 1 : id >= 0 ? id * 32 + __ffs((int)cd) - 1 : -1;
+        }
         // a walk that found nothing contributes weight 0; its position only has to be valid
         ProjScan l, rr, u, d;
         l.pos = xl < 0 ? x : xl; rr.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
@@ -591,16 +734,16 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_finish(
         rr.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
         u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
         d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
+        const float a0 = o0[row + l.pos], b0 = o0[row + rr.pos], c0 = o0[(int64_t)u.pos * s1.h + x], d0 = o0[(int64_t)d.pos * s1.h + x];
+        const float a1 = o1[row + l.pos], b1 = o1[row + rr.pos], c1 = o1[(int64_t)u.pos * s1.h + x], d1 = o1[(int64_t)d.pos * s1.h + x];
         if (l.cnt + rr.cnt + u.cnt + d.cnt <= 0.0f) continue;
         const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
         const float rt = (rr.cnt > 0.0f) ? 1.0f : 0.0f;
         const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
         const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
         const float den = lt + rt + ut + dt;
-        o0[row + x] = (lt * o0[row + l.pos] + rt * o0[row + rr.pos] + ut * o0[(int64_t)u.pos * s1.h + x] +
-                       dt * o0[(int64_t)d.pos * s1.h + x]) / den;
-        o1[row + x] = (lt * o1[row + l.pos] + rt * o1[row + rr.pos] + ut * o1[(int64_t)u.pos * s1.h + x] +
-                       dt * o1[(int64_t)d.pos * s1.h + x]) / den;
+        o0[row + x] = (lt * a0 + rt * b0 + ut * c0 + dt * d0) / den;
+        o1[row + x] = (lt * a1 + rt * b1 + ut * c1 + dt * d1) / den;
     }
 }
 
@@ -653,64 +796,72 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void proj_backward(
     }
 }
 
-// Geometry and workspace sizes of a call; false when the frame is beyond what the tables can index.
+// Geometry and workspace sizes of a call; false when the frame is beyond what the records can index.
 struct ProjSizes { size_t words, bit_words, plane_floats; };
 static bool proj_geometry(int batch, int h, int w, ProjGeom* g, ProjSizes* z) {
-    if (batch <= 0 || h <= 0 || w <= 0 || h > 32767 || w > 32767) return false;    // displacements are stored as int16
+    if (batch <= 0 || h <= 0 || w <= 0 || h > 32767 || w > 32767) return false;
     g->h = h; g->w = w;
     g->tiles_x = (w + PROJ_TW - 1) / PROJ_TW;
     g->tiles_y = (h + PROJ_TH - 1) / PROJ_TH;
     const int64_t nt = (int64_t)g->tiles_x * g->tiles_y * batch;
-    g->sup_x = (w + PROJ_SUP_W - 1) / PROJ_SUP_W;
-    g->sup_y = (h + PROJ_SUP_H - 1) / PROJ_SUP_H;
-    g->nsup = g->sup_x * g->sup_y;
-    const int64_t ns = (int64_t)g->nsup * batch;
-    if (nt > (1 << 24) || ns > (1 << 22)) return false;
+    if (nt > (1 << 24)) return false;
     g->ntiles = (int)nt;
     g->rmw = (w + 31) / 32;
-    g->cmw = (g->tiles_y * PROJ_TH + 31) / 32;              // whole tiles: K1 stores 16-bit halves
-    z->bit_words = (size_t)batch * ((size_t)h * g->rmw + (size_t)w * g->cmw);
+    g->cmw = (((g->tiles_y * PROJ_TH + 31) / 32) + 3) & ~3;     // whole tiles (K1 stores 16-bit halves), whole 16-byte groups
+    const size_t row_words = ((size_t)batch * h * g->rmw + 3) & ~(size_t)3;
+    z->bit_words = row_words + (size_t)batch * w * g->cmw;
     if (z->bit_words > (size_t)INT_MAX) return false;
     g->rowmap = 0;
-    g->colmap = batch * h * g->rmw;
-    g->off_sup = PROJ_WS_HDR;
-    g->off_blk = g->off_sup + 4 * (int)ns;
-    g->off_holes = g->off_blk + 4 * PROJ_SUP_BLOCKS * (int)ns;
-    z->words = (size_t)g->off_holes + (size_t)nt;
+    g->colmap = (int)row_words;
+    g->off_tile = PROJ_WS_HDR;
+    g->off_list = g->off_tile + PROJ_TILE_WORDS * g->ntiles;
+    z->words = (size_t)g->off_list + (size_t)nt;
+#ifdef PROJ_STAMPS
+    z->words += 2 + 16 * (size_t)nt;
+#endif
     z->plane_floats = (size_t)3 * batch * h * w;
     return true;
 }
 
 struct ProjBuffers { int* words; int* bits; float* planes; };
 static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
-    // the header and the scratch planes carry state between calls and start at zero; the tables and the
-    // bitmaps are rewritten by every call
+    // the header, the tile records and the scratch planes carry state between calls and start at zero;
+    // the list and the bitmaps are rewritten by every call
     p->words = static_cast<int*>(ws_get(st, WS_PROJ_WORDS, z.words * sizeof(int), true, nullptr));
     p->bits = static_cast<int*>(ws_get(st, WS_PROJ_BITS, z.bit_words * sizeof(int), false, nullptr));
     p->planes = static_cast<float*>(ws_get(st, WS_PROJ_PLANES, z.plane_floats * sizeof(float), true, nullptr));
     return p->words && p->bits && p->planes;
 }
 
+// every in-plane element offset of a [*, *, h, w] tensor with row stride sh fits 31 bits
+static bool fits32(int64_t sh, int h, int w) { return sh >= 0 && sh * (int64_t)(h - 1) + w < ((int64_t)1 << 31); }
+
 // s1 = strides of `out` (the reference binding shares them with the input flow)
 template <bool DEPTH, bool UP>
-static int project_forward(const ProjFlow& flow, const float* in2, float* count, float* out, int batch, int h, int w,
-                           int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
+static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, float m0, float m1, const float* in2,
+                           float* count, float* out, int batch, int h, int w, int fillhole, vfi_strides s1,
+                           vfi_strides s2, vfi_strides sc, hipStream_t st) {
     ProjGeom g;
     ProjSizes z;
     if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
+    if (!fits32(sf.h, UP ? hq : h, UP ? wq : w) || !fits32(s1.h, h, w) || !fits32(sc.h, h, w) || (DEPTH && !fits32(s2.h, h, w)))
+        return VFI_ERR_SHAPE;
     ProjBuffers p;
     if (!proj_buffers(st, z, &p)) return VFI_ERR_LAUNCH;
-    const int nsup_all = g.nsup * batch;
-    const unsigned long long cost_limit = (unsigned long long)PROJ_COST_LIMIT * PROJ_SUP_BLOCKS * (unsigned long long)nsup_all;
-    hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(nsup_all), dim3(PROJ_SCAN_THREADS), 0, st, flow, in2, g, s2, p.words,
-                       p.planes, (int64_t)z.plane_floats);
+    ProjSrc src;
+    src.flow = flow; src.depth = in2;
+    src.fb = sf.b; src.fc = sf.c; src.db = DEPTH ? s2.b : 0;
+    src.fh = (int)sf.h; src.dh = DEPTH ? (int)s2.h : 0;
+    src.hq = hq; src.wq = wq; src.m0 = m0; src.m1 = m1;
+    hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
+                       (int64_t)z.plane_floats);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL((proj_pull<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, flow, in2, count, out, g, s1,
-                       s2, sc, p.words, p.bits, p.planes, cost_limit);
+    hipLaunchKernelGGL((proj_pull<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+                       (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, p.words, p.bits, p.planes);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
-    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_THREADS), 0, st, count, out, g, s1, sc, p.words, p.bits,
-                       p.planes, fillhole);
+    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles < 512 ? g.ntiles : 512), dim3(PROJ_FIN_THREADS), 0, st, count, out, g,
+                       s1, sc, p.words, p.bits, p.planes, fillhole);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return VFI_OK;
 }
@@ -733,6 +884,19 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void flow_upsample4(
 
 using namespace vfi;
 
+#ifdef PROJ_STAMPS
+extern "C" int vfi_dev_projection_stamps(int batch, int h, int w, vfi_stream_t stream, unsigned long long* host_out) {
+    ProjGeom g;
+    ProjSizes z;
+    if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
+    ProjBuffers p;
+    if (!proj_buffers((hipStream_t)stream, z, &p)) return VFI_ERR_LAUNCH;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(host_out, p.words + g.off_list + g.ntiles + (g.ntiles & 1), (size_t)g.ntiles * 64, hipMemcpyDeviceToHost) == hipSuccess
+               ? VFI_OK : VFI_ERR_LAUNCH;
+}
+#endif
+
 extern "C" int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stream) {
     ProjGeom g;
     ProjSizes z;
@@ -744,16 +908,16 @@ extern "C" int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stre
 extern "C" int vfi_flowprojection_forward(const float* input1, float* count, float* output, int batch, int h, int w,
                                            int fillhole, vfi_strides s1, vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !count || !output) return VFI_ERR_SHAPE;
-    const ProjFlow flow{input1, s1, 0, 0, 1.0f, 1.0f};
-    return project_forward<false, false>(flow, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc, (hipStream_t)stream);
+    return project_forward<false, false>(input1, s1, 0, 0, 1.0f, 1.0f, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc,
+                                         (hipStream_t)stream);
 }
 
 extern "C" int vfi_depthflowprojection_forward(const float* input1, const float* input2, float* count, float* output,
                                                 int batch, int h, int w, int fillhole, vfi_strides s1, vfi_strides s2,
                                                 vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !count || !output) return VFI_ERR_SHAPE;
-    const ProjFlow flow{input1, s1, 0, 0, 1.0f, 1.0f};
-    return project_forward<true, false>(flow, input2, count, output, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
+    return project_forward<true, false>(input1, s1, 0, 0, 1.0f, 1.0f, input2, count, output, batch, h, w, fillhole, s1, s2, sc,
+                                        (hipStream_t)stream);
 }
 
 // ---- fused glue: the network's quarter-resolution flow goes straight into the splat
@@ -771,9 +935,8 @@ extern "C" int vfi_flowprojection_forward_up4(const float* flow_q, float* count,
                                                vfi_strides so, vfi_stream_t stream) {
     if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !count || !output)
         return VFI_ERR_SHAPE;
-    const ProjFlow flow{flow_q, sq, hq, wq, mul0, mul1};
-    return project_forward<false, true>(flow, nullptr, count, output, batch, 4 * hq, 4 * wq, fillhole, so, so, sc,
-                                        (hipStream_t)stream);
+    return project_forward<false, true>(flow_q, sq, hq, wq, mul0, mul1, nullptr, count, output, batch, 4 * hq, 4 * wq, fillhole,
+                                        so, so, sc, (hipStream_t)stream);
 }
 
 extern "C" int vfi_depthflowprojection_forward_up4(const float* flow_q, const float* input2, float* count, float* output,
@@ -782,9 +945,8 @@ extern "C" int vfi_depthflowprojection_forward_up4(const float* flow_q, const fl
                                                     vfi_stream_t stream) {
     if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !input2 || !count || !output)
         return VFI_ERR_SHAPE;
-    const ProjFlow flow{flow_q, sq, hq, wq, mul0, mul1};
-    return project_forward<true, true>(flow, input2, count, output, batch, 4 * hq, 4 * wq, fillhole, so, s2, sc,
-                                       (hipStream_t)stream);
+    return project_forward<true, true>(flow_q, sq, hq, wq, mul0, mul1, input2, count, output, batch, 4 * hq, 4 * wq, fillhole,
+                                       so, s2, sc, (hipStream_t)stream);
 }
 
 extern "C" int vfi_flowprojection_backward(const float* input1, const float* count, const float* gradoutput,
