@@ -47,6 +47,8 @@ for name, a, b in (("prologue+loop", t0, t1), ("barrier+sums", t1, t2), ("epilog
     print("%-14s median %8.0f cycles (%.0f %% of life)" % (name, np.median(d), 100.0 * np.median(d) / np.median(cyc)))
 hw = buf[:, 6].astype(np.int64)
 xcc = buf[:, 7].astype(np.int64) & 0xf
+ta = (buf[:, 7].astype(np.int64) >> 8).astype(np.float64)
+print("record arrived + LDS zeroed after: p10 %.0f p50 %.0f p90 %.0f max %.0f cycles" % (np.percentile(ta, 10), np.median(ta), np.percentile(ta, 90), ta.max()))
 cu = (hw >> 8) & 0xf
 se = (hw >> 13) & 0x7
 sh = (hw >> 12) & 0x1

@@ -20,8 +20,8 @@
 //   K1  proj_pull    one workgroup per output tile: walks its source rectangle (for a smooth field: the tile
 //                    shifted by the flow and a few pixels larger, ~1.3 source pixels per output pixel),
 //                    accumulates in LDS and writes count and the normalised flow once, coalesced, plus two
-//                    bitmaps of "count != 0"; lists the tile if it has holes.
-//   K2  proj_finish  hole filling for the listed tiles (bitmap searches in registers instead of the
+//                    bitmaps of "count != 0" and whether the tile has holes.
+//   K2  proj_finish  hole filling for the tiles that have holes (bitmap searches in registers instead of the
 //                    reference's cell-by-cell walks); resets the per-call state.
 // K1 writes every cell of count and output, so callers need not zero-fill them (the reference's
 // callers must: its splat accumulates into them).  Nothing of a call's state crosses to the host and
@@ -49,6 +49,10 @@
 #include "bitwalk.h"
 #include "workspace.h"
 
+#ifndef PROJ_DEV_SKIP
+#define PROJ_DEV_SKIP 0
+#endif
+
 #include <limits.h>
 
 namespace vfi {
@@ -63,16 +67,15 @@ namespace vfi {
 
 // workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
 // read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by K1, read by K2 and by
-// the next call's K0); [3] length of the list of tiles with holes (reset by K0, appended by K1, read by K2).
+// the next call's K0).
 // Then one 8-word record per output tile: its source rectangle as 32767 - x0, 32767 - y0, x1 + 1, y1 + 1 and
 // the bits of the largest |value addend| and |count addend| that reach it -- all merged with atomicMax by K0,
-// so 0 = nothing; K1 reads its record and zeroes it again.  Then the list of tiles with holes.
+// so 0 = nothing; K1 reads its record and zeroes it again.  Then one word per tile from K1 to K2: has it holes.
 // workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and one packed
 // along columns (colmap[b][x][y/32], lines padded to whole 16-byte groups), written by K1 for the hole filler.
 #define PROJ_WS_HDR 16
 #define PROJ_WS_FLAG 0
 #define PROJ_WS_DIRTY 2
-#define PROJ_WS_NLIST 3
 #define PROJ_TILE_WORDS 8
 
 // rmw / cmw: 32-bit words per image row / column of the two bitmaps; rowmap / colmap: their word offsets
@@ -201,61 +204,13 @@ __device__ __forceinline__ int row16_max(int v) {
 }
 #undef PROJ_ROW_STEP
 
-// K0: one wave per 64 x 16 pixels of the SOURCE frame (lane = x, 16 rows; all loads of the wave in flight at
-// once).  Per 16x16 block: the range of (L - x) and of (T - y) over its valid pixels; from it the output tiles the
-// block can reach, and for each of them the part of the block that can -- merged into that tile's source
-// rectangle with atomicMax (fields stored so that 0 means "nothing").
-template <bool DEPTH, bool UP>
-__global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __restrict__ ws, float* __restrict__ planes,
-                                                int64_t plane_floats) {
-    if (ws[PROJ_WS_DIRTY] != 0) {
-        // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
-        // a slice per workgroup (this call's K1 rewrites the word)
-        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
-        for (int64_t i = lo + threadIdx.x; i < hi; i += 64) planes[i] = 0.0f;
-    }
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    if (tile == 0 && lane == 0) ws[PROJ_WS_NLIST] = 0;      // K1 lists the tiles with holes for K2
-    const int per_img = g.tiles_x * g.tiles_y;
-    const int b = tile / per_img;
-    const int trem = tile - b * per_img;
-    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
-    const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH;
-    const int xc = min(x, g.w - 1);
-    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
-    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
-    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
-    constexpr int GROUP = UP ? 4 : PROJ_TH;                 // rows whose loads are issued together
-#pragma unroll 1
-    for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
-        ProjPix<UP> raw[GROUP];
-#pragma unroll
-        for (int k = 0; k < GROUP; ++k) raw[k] = pix_load<DEPTH, UP>(src, pl, xc, 0, min(y0 + r0 + k, g.h - 1));
-#pragma unroll
-        for (int k = 0; k < GROUP; ++k) {
-            const int y = y0 + r0 + k;
-            float fx, fy;
-            pix_flow<UP>(src, raw[k], xc, min(y, g.h - 1), fx, fy);
-            int L, T;
-            const bool valid = pix_target(fx, fy, x, y, wbits, hbits, L, T) && x < g.w && y < g.h;
-            const int dl = L - x, dt = T - y;
-            dlmin = min(dlmin, valid ? dl : INT_MAX); dlmax = max(dlmax, valid ? dl : INT_MIN);
-            dtmin = min(dtmin, valid ? dt : INT_MAX); dtmax = max(dtmax, valid ? dt : INT_MIN);
-            // the addends' magnitudes; non-negative floats order like their bit patterns
-            const float av = DEPTH ? fmaxf(fabsf(raw[k].d * fx), fabsf(raw[k].d * fy)) : fmaxf(fabsf(fx), fabsf(fy));
-            vbits = max(vbits, valid ? __float_as_int(av) : 0);
-            if constexpr (DEPTH) cbits = max(cbits, valid ? __float_as_int(fabsf(raw[k].d)) : 0);
-            else cbits = max(cbits, valid ? __float_as_int(1.0f) : 0);
-        }
-    }
-    dlmin = row16_min(dlmin); dlmax = row16_max(dlmax);
-    dtmin = row16_min(dtmin); dtmax = row16_max(dtmax);
-    vbits = row16_max(vbits); cbits = row16_max(cbits);
-    // The wave's four blocks sit side by side (lanes 15, 31, 47, 63 speak for them) and mostly feed the same two
-    // or three output tiles: per tile of the union of their ranges the four parts are merged in registers and the
-    // record is updated by ONE atomic instruction (lane k = field k) -- the atomics are the expensive part of
-    // this kernel (one wave instruction per ~50 ns per CU at the memory side, whatever its lane count).
+// The tail of K0.  Lanes 15, 31, 47, 63 of the wave speak for four 16x16 blocks that sit side by side (x = the
+// block's last column, y0 = its first row) and mostly feed the same two or three output tiles: per tile of the
+// union of their ranges the four parts are merged in registers and the record is updated by ONE atomic
+// instruction (lane k = field k) -- the atomics are the expensive part of this kernel (one wave instruction
+// per ~50 ns per CU at the memory side, whatever its lane count).
+__device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict__ ws, int b, int lane, int x, int y0,
+                                             int dlmin, int dlmax, int dtmin, int dtmax, int vbits, int cbits) {
     const bool any = dlmin != INT_MAX;
     const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
     // top-left targets of the block lie in [X0, X1] x [Y0, Y1]; a target (L, T) feeds columns L, L + 1, rows T, T + 1
@@ -298,6 +253,134 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
         }
 }
 
+// K0: one wave per 64 x 16 pixels of the SOURCE frame (lane = x, 16 rows; all loads of the wave in flight at
+// once).  Per 16x16 block: the range of (L - x) and of (T - y) over its valid pixels; from it the output tiles the
+// block can reach, and for each of them the part of the block that can -- merged into that tile's source
+// rectangle with atomicMax (fields stored so that 0 means "nothing").
+template <bool DEPTH, bool UP>
+__global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __restrict__ ws, float* __restrict__ planes,
+                                                int64_t plane_floats) {
+    if (ws[PROJ_WS_DIRTY] != 0) {
+        // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
+        // a slice per workgroup (this call's K1 rewrites the word)
+        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 64) planes[i] = 0.0f;
+    }
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH;
+    const int xc = min(x, g.w - 1);
+    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
+    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
+    constexpr int GROUP = UP ? 4 : PROJ_TH;                 // rows whose loads are issued together
+#pragma unroll 1
+    for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
+        ProjPix<UP> raw[GROUP];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) raw[k] = pix_load<DEPTH, UP>(src, pl, xc, 0, min(y0 + r0 + k, g.h - 1));
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) {
+            const int y = y0 + r0 + k;
+            float fx, fy;
+            pix_flow<UP>(src, raw[k], xc, min(y, g.h - 1), fx, fy);
+            int L, T;
+            const bool valid = pix_target(fx, fy, x, y, wbits, hbits, L, T) && x < g.w && y < g.h;
+            const int dl = L - x, dt = T - y;
+            dlmin = min(dlmin, valid ? dl : INT_MAX); dlmax = max(dlmax, valid ? dl : INT_MIN);
+            dtmin = min(dtmin, valid ? dt : INT_MAX); dtmax = max(dtmax, valid ? dt : INT_MIN);
+            // the addends' magnitudes; non-negative floats order like their bit patterns
+            const float av = DEPTH ? fmaxf(fabsf(raw[k].d * fx), fabsf(raw[k].d * fy)) : fmaxf(fabsf(fx), fabsf(fy));
+            vbits = max(vbits, valid ? __float_as_int(av) : 0);
+            if constexpr (DEPTH) cbits = max(cbits, valid ? __float_as_int(fabsf(raw[k].d)) : 0);
+            else cbits = max(cbits, valid ? __float_as_int(1.0f) : 0);
+        }
+    }
+    dlmin = row16_min(dlmin); dlmax = row16_max(dlmax);
+    dtmin = row16_min(dtmin); dtmax = row16_max(dtmax);
+    vbits = row16_max(vbits); cbits = row16_max(cbits);
+    scan_scatter(g, ws, b, lane, x, y0, dlmin, dlmax, dtmin, dtmax, vbits, cbits);
+}
+
+// K0 for a full-resolution flow: the same, with 16-byte lanes (a walk with 4-byte lanes reaches ~4 TB/s on this
+// chip, one with 16-byte lanes ~5.3).  A workgroup of four waves covers 256 x 16 pixels -- four tiles side by
+// side; a lane owns four consecutive pixels, a wave four rows; the 16x16 blocks' ranges are combined across
+// the waves in LDS, then wave w scatters the four blocks of tile column w exactly as above.
+typedef int proj_v4i __attribute__((ext_vector_type(4)));
+typedef float proj_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ proj_v4f buf_f32x4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(proj_v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+#define PROJ_QUAD_STEP(OP, SEL) v = OP(v, __builtin_amdgcn_update_dpp(v, v, SEL, 0xf, 0xf, false))
+__device__ __forceinline__ int quad_min(int v) { PROJ_QUAD_STEP(min, 0xb1); PROJ_QUAD_STEP(min, 0x4e); return v; }   // quad_perm [1,0,3,2], [2,3,0,1]
+__device__ __forceinline__ int quad_max(int v) { PROJ_QUAD_STEP(max, 0xb1); PROJ_QUAD_STEP(max, 0x4e); return v; }
+#undef PROJ_QUAD_STEP
+
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int groups_x, int* __restrict__ ws,
+                                                  float* __restrict__ planes, int64_t plane_floats) {
+    if (ws[PROJ_WS_DIRTY] != 0) {
+        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
+    }
+    __shared__ int sblk[16][6];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 96) sblk[tid / 6][tid % 6] = (tid % 6 == 0 || tid % 6 == 2) ? INT_MAX : (tid % 6 == 1 || tid % 6 == 3) ? INT_MIN : 0;
+    const int per_img = groups_x * g.tiles_y;
+    const int b = blockIdx.x / per_img;
+    const int rem = blockIdx.x - b * per_img;
+    const int tyi = rem / groups_x, gxi = rem - tyi * groups_x;
+    const int x0 = gxi * 4 * PROJ_TW + 4 * lane, y0 = tyi * PROJ_TH, yw = y0 + 4 * wave;
+    const ProjPlanes pl = proj_planes<DEPTH, false>(src, b, g.h, g.w);
+    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
+    proj_v4f qx[4], qy[4], qd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int so = min(yw + r, g.h - 1) * src.fh * 4;
+        qx[r] = buf_f32x4(pl.f0, x0 * 4, so);
+        qy[r] = buf_f32x4(pl.f1, x0 * 4, so);
+        if constexpr (DEPTH) qd[r] = buf_f32x4(pl.d, x0 * 4, min(yw + r, g.h - 1) * src.dh * 4);
+    }
+    __syncthreads();
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j, y = yw + r;
+            const float fx = qx[r][j], fy = qy[r][j];
+            int L, T;
+            const bool valid = pix_target(fx, fy, x, y, wbits, hbits, L, T) && x < g.w && y < g.h;
+            if (valid) {
+                dlmin = min(dlmin, L - x); dlmax = max(dlmax, L - x);
+                dtmin = min(dtmin, T - y); dtmax = max(dtmax, T - y);
+                // the addends' magnitudes; non-negative floats order like their bit patterns
+                const float av = DEPTH ? fmaxf(fabsf(qd[r][j] * fx), fabsf(qd[r][j] * fy)) : fmaxf(fabsf(fx), fabsf(fy));
+                vbits = max(vbits, __float_as_int(av));
+                cbits = max(cbits, DEPTH ? __float_as_int(fabsf(qd[r][j])) : __float_as_int(1.0f));
+            }
+        }
+    // a block is four lanes wide
+    dlmin = quad_min(dlmin); dlmax = quad_max(dlmax); dtmin = quad_min(dtmin); dtmax = quad_max(dtmax);
+    vbits = quad_max(vbits); cbits = quad_max(cbits);
+    if ((lane & 3) == 0 && dlmin != INT_MAX) {
+        int* e = sblk[lane >> 2];
+        atomicMin(&e[0], dlmin); atomicMax(&e[1], dlmax); atomicMin(&e[2], dtmin); atomicMax(&e[3], dtmax);
+        atomicMax(&e[4], vbits); atomicMax(&e[5], cbits);
+    }
+    __syncthreads();
+    // wave w: the four blocks of tile column w, spoken for by lanes 15, 31, 47, 63 as in proj_scan
+    const int* e = sblk[4 * wave + (lane >> 4)];
+    const int xb = (gxi * 4 + wave) * PROJ_TW + (lane >> 4) * PROJ_BLK + 15;      // the block's last column
+    const bool speaker = (lane & 15) == 15 && xb - 15 < g.w;
+    scan_scatter(g, ws, b, lane, xb, y0, speaker ? e[0] : INT_MAX, e[1], e[2], e[3], e[4], e[5]);
+}
+
 // the two halves of a packed sum, exactly: S = hi * 2^32 + lo with both in int32
 __device__ __forceinline__ unsigned long long pack2(int hi, int lo) {
     return ((unsigned long long)(unsigned)hi << 32) + (unsigned long long)(long long)lo;
@@ -316,10 +399,12 @@ template <> struct ProjCountCell<true> { typedef unsigned long long type; };    
 // this equals adding every addend to its four targets).  At the last column / row of the frame R == L / B == T:
 // the reference adds twice there (flowprojection_cuda_kernel.cu:72-73), so does the sum below.
 //
-// Workgroup size: the kernel is bound by instruction issue, not by memory, and every tile costs the same, so
-// what matters is that ALL tiles are resident at once (a 1080p frame has 2232 tiles; 8 workgroups of 256
-// threads per CU would hold 2048 and leave a second round that doubles the time).  128 threads per tile:
-// up to 9 workgroups per CU within the LDS, 8 output cells and ~11 source pixels per thread.
+// Workgroup size: every tile costs the same and all start within a microsecond, so what matters is that ALL
+// tiles are resident at once (a 1080p frame has 2232 tiles; 8 workgroups of 256 threads per CU would hold
+// 2048 and leave a second round).  128 threads per tile: 9 workgroups per CU within the LDS.
+// Memory: the kernel is bound by the memory system (in-kernel stamps, tools/proj_stamps.py: the later a
+// workgroup's requests are queued, the longer it lives), so the flow is read and count / output are written
+// with 16-byte lanes: a lane owns four consecutive pixels.
 #ifndef PROJ_PULL_THREADS
 #define PROJ_PULL_THREADS 128
 #endif
@@ -327,29 +412,53 @@ template <> struct ProjCountCell<true> { typedef unsigned long long type; };    
 #define PROJ_PULL_WAVES 5           // 9 workgroups x 2 waves per CU
 #endif
 #ifndef PROJ_PULL_CH
-#define PROJ_PULL_CH 5              // source pixels whose loads a thread has in flight
+#define PROJ_PULL_CH 2              // loads in flight per lane: CH x 4 pixels (CH x 1 through the scalar walk)
 #endif
 #define PROJ_AW (PROJ_TW + 1)
 #define PROJ_AH (PROJ_TH + 1)
-#define PROJ_CELLS (PROJ_AH * PROJ_AW)
+#define PROJ_VS 66                                  // grid row pitch of the 8-byte planes: rows start 16-byte aligned
+#define PROJ_CS4 68                                 // ... of the 4-byte count plane
 #define PROJ_NW (PROJ_PULL_THREADS / 64)            // waves per workgroup
-#define PROJ_ROWS (PROJ_TH / PROJ_NW)               // consecutive tile rows per wave in the epilogue
-#define PROJ_ACCC_OFF ((PROJ_CELLS * 8 + 15) & ~15)
+#define PROJ_EPI_ITERS (PROJ_TH / (4 * PROJ_NW))    // a wave writes four rows per instruction (16 lanes x 16 bytes each)
 template <bool DEPTH> struct ProjLds {
-    static constexpr int acc_bytes = (PROJ_ACCC_OFF + PROJ_CELLS * (DEPTH ? 8 : 4) + 15) & ~15;
-    static constexpr int total = acc_bytes + PROJ_TW * 4 + 16;     // + column masks + two counters
+    static constexpr int cs = DEPTH ? PROJ_VS : PROJ_CS4;                      // count plane pitch
+    static constexpr int accc_off = PROJ_AH * PROJ_VS * 8;
+    static constexpr int acc_bytes = accc_off + PROJ_AH * cs * (DEPTH ? 8 : 4);
+    static constexpr int total = acc_bytes + PROJ_TH * 8 + 16;                 // + row bitmaps + three counters
 };
 
-template <bool DEPTH, bool UP>
+// one source pixel into the grid
+template <bool DEPTH>
+__device__ __forceinline__ void pull_add(unsigned long long* accv, typename ProjCountCell<DEPTH>::type* accc,
+                                         float fx, float fy, float d, int px, int py, bool on, unsigned wbits, unsigned hbits,
+                                         int cx, int cy, float sv, float scn) {
+    int L, T;
+    const bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
+    const unsigned c = (unsigned)(L - cx), r = (unsigned)(T - cy);
+#if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 3
+    if (valid && on && c < PROJ_AW && r < PROJ_AH && sv == 12345.0f) {
+#else
+    if (valid && on && c < PROJ_AW && r < PROJ_AH) {
+#endif
+        // addend * 2^k is exact in float (power-of-two scale)
+        const float ax = DEPTH ? d * fx : fx, ay = DEPTH ? d * fy : fy;        // (:75-88; depth :74-91)
+        atomicAdd(&accv[r * PROJ_VS + c], pack2(__float2int_rn(ax * sv), __float2int_rn(ay * sv)));
+        if constexpr (DEPTH) atomicAdd(&accc[r * PROJ_VS + c], pack2(1, __float2int_rn(d * scn)));
+        else atomicAdd(&accc[r * PROJ_CS4 + c], 1u);
+    }
+}
+
+// VEC: the flow (and depth) rows are 16-byte aligned, so a lane can load four pixels at once
+template <bool DEPTH, bool UP, bool VEC>
 __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
-    int64_t cb, int ch, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes) {
+    int64_t cb, int ch, int vec_ok, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes) {
     typedef typename ProjCountCell<DEPTH>::type ccell;
     __shared__ uint4 lds[ProjLds<DEPTH>::total / 16];
     unsigned long long* accv = reinterpret_cast<unsigned long long*>(lds);
-    ccell* accc = reinterpret_cast<ccell*>(reinterpret_cast<char*>(lds) + PROJ_ACCC_OFF);
-    unsigned* s_colm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::acc_bytes);
-    int* s_misc = reinterpret_cast<int*>(s_colm + PROJ_TW);        // [0] most addends in a cell, [1] holes, [2] negative counts
+    ccell* accc = reinterpret_cast<ccell*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::accc_off);
+    unsigned* s_rowbits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::acc_bytes);   // [16][2]
+    int* s_misc = reinterpret_cast<int*>(s_rowbits + 2 * PROJ_TH);     // [0] most addends in a cell, [1] holes, [2] negative counts
     const int tile = blockIdx.x;
     const int per_img = g.tiles_x * g.tiles_y;
     const int b = tile / per_img;
@@ -379,8 +488,8 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         float* o1 = o0 + npx;
         float* cn = o1 + npx;
         const int x = ox0 + lane;
-        for (int r = 0; r < PROJ_ROWS; ++r) {
-            const int y = oy0 + wave * PROJ_ROWS + r;
+        for (int r = 0; r < PROJ_TH / PROJ_NW; ++r) {
+            const int y = oy0 + wave * (PROJ_TH / PROJ_NW) + r;
             if (x >= g.w || y >= g.h) continue;
             float fx, fy;
             const ProjPix<UP> p = pix_load<DEPTH, UP>(src, pl, x, 0, y);
@@ -400,6 +509,9 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     for (int i = tid; i < ProjLds<DEPTH>::total / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     if (tid < 6) entry[tid] = 0;                            // every thread has read the record: empty for the next call
+#ifdef PROJ_STAMPS
+    const unsigned long long st_ta = __builtin_amdgcn_s_memtime() + (e0 & 0);      // (after the record has arrived)
+#endif
 
     const int ux0 = 32767 - e0, uy0 = 32767 - e1;
     const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
@@ -411,50 +523,76 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
     int kv = max(-100, min(100, PROJ_ADD_BITS - ev)), kc = max(-100, min(100, PROJ_ADD_BITS - ec));
 
-    const int x = ox0 + lane;
-    const bool xlast = x == g.w - 1;                        // R == L there: the column adds twice
-    const int yl0 = wave * PROJ_ROWS;
-    unsigned long long sumv[PROJ_ROWS];
-    ccell sumc[PROJ_ROWS];
+    // epilogue geometry: a lane owns four consecutive cells of a row, 16 lanes a row, a wave four rows
+    const int q = lane & 15, rw = lane >> 4;
+    const int xq = ox0 + 4 * q;
+    float resx[PROJ_EPI_ITERS][4], resy[PROJ_EPI_ITERS][4], resc[PROJ_EPI_ITERS][4];    // the tile's sums, not yet normalised
     for (int attempt = 0;; ++attempt) {
         const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
-        // The rectangle is walked in strips of up to 64 columns.  A full strip: lane = column, the workgroup's
-        // waves take its rows in turn (row base and flow row pointer advance on the scalar unit: no per-pixel
-        // index arithmetic).  The last, narrower strip packs 64 / width rows into a wave the same way.  CH
-        // pixels' loads are in flight per lane.
-        constexpr int CH = UP ? 2 : PROJ_PULL_CH;
-        for (int cs = 0; cs < uw && uh > 0; cs += 64) {
-            const int width = min(64, uw - cs), rpi = 64 / width;      // rows per wave instruction
-            const int lr = lane / width, lc = lane - lr * width;
-            const int px = ux0 + cs + lc;
-            const bool lane_on = lr < rpi;                              // (rows past the rectangle are loaded -- past the plane
-                                                                        //  they read as 0 -- and ignored)
-            const int step = PROJ_NW * rpi;
-            for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
-                ProjPix<UP> raw[CH];
+        // The rectangle is walked in strips of up to 64 lanes.  A full strip: the workgroup's waves take its rows
+        // in turn (row base and flow row pointer advance on the scalar unit: no per-pixel index arithmetic).  A
+        // narrower strip packs 64 / width rows into a wave the same way.  Rows past the rectangle are not loaded.
+        constexpr int CH = PROJ_PULL_CH;
+        if constexpr (!VEC) {
+            for (int cs = 0; cs < uw && uh > 0; cs += 64) {
+                const int width = min(64, uw - cs), rpi = 64 / width;      // rows per wave instruction
+                const int lr = lane / width, lc = lane - lr * width;
+                const int px = ux0 + cs + lc;
+                const bool lane_on = lr < rpi;
+                const int step = PROJ_NW * rpi;
+                for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
+                    ProjPix<UP> raw[CH];
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
+                    for (int k = 0; k < CH; ++k) {
 #pragma unroll
-                    for (int q = 0; q < (UP ? 8 : 2); ++q) raw[k].v[q] = 0.0f;
-                    raw[k].d = 0.0f;
-                    if (row0 + k * step < uh) raw[k] = pix_load<DEPTH, UP>(src, pl, px, lr, uy0 + row0 + k * step);   // (wave-uniform test)
+                        for (int j = 0; j < (UP ? 8 : 2); ++j) raw[k].v[j] = 0.0f;
+                        raw[k].d = 0.0f;
+                        if (row0 + k * step < uh) raw[k] = pix_load<DEPTH, UP>(src, pl, px, lr, uy0 + row0 + k * step);    // (past the plane: reads 0)
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int rowk = row0 + k * step + lr;
+                        const int py = uy0 + rowk;
+                        float fx, fy;
+                        pix_flow<UP>(src, raw[k], px, py, fx, fy);
+                        pull_add<DEPTH>(accv, accc, fx, fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn);
+                    }
                 }
+            }
+        } else {
+            const int ux0a = ux0 & ~3;                                      // quads start at multiples of four pixels
+#if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 1
+            const int nq = 0;
+#else
+            const int nq = uh > 0 ? (ux0 + uw - 1 - ux0a) / 4 + 1 : 0;      // quads per row
+#endif
+            for (int cs = 0; cs < nq; cs += 64) {
+                const int width = min(64, nq - cs), rpi = 64 / width;
+                const int lr = lane / width, lc = lane - lr * width;
+                const int px = ux0a + 4 * (cs + lc);
+                const bool lane_on = lr < rpi;
+                const int step = PROJ_NW * rpi;
+                const int vo = (lr * src.fh + px) * 4, vod = (lr * src.dh + px) * 4;
+                for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
+                    proj_v4f qx[CH], qy[CH], qd[CH];
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const int rowk = row0 + k * step + lr;
-                    const int py = uy0 + rowk;
-                    float fx, fy;
-                    pix_flow<UP>(src, raw[k], px, py, fx, fy);
-                    int L, T;
-                    const bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
-                    const unsigned c = (unsigned)(L - (ox0 - 1)), r = (unsigned)(T - (oy0 - 1));
-                    if (valid && lane_on && rowk < uh && c < PROJ_AW && r < PROJ_AH) {
-                        const int idx = r * PROJ_AW + c;
-                        // addend * 2^k is exact in float (power-of-two scale)
-                        const float ax = DEPTH ? raw[k].d * fx : fx, ay = DEPTH ? raw[k].d * fy : fy;   // (:75-88; depth :74-91)
-                        atomicAdd(&accv[idx], pack2(__float2int_rn(ax * sv), __float2int_rn(ay * sv)));
-                        if constexpr (DEPTH) atomicAdd(&accc[idx], pack2(1, __float2int_rn(raw[k].d * scn)));
-                        else atomicAdd(&accc[idx], 1u);
+                    for (int k = 0; k < CH; ++k) {
+                        qx[k] = qy[k] = qd[k] = proj_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                        if (row0 + k * step < uh) {                         // (wave-uniform test)
+                            const int yu = uy0 + row0 + k * step;
+                            qx[k] = buf_f32x4(pl.f0, vo, yu * src.fh * 4);
+                            qy[k] = buf_f32x4(pl.f1, vo, yu * src.fh * 4);
+                            if constexpr (DEPTH) qd[k] = buf_f32x4(pl.d, vod, yu * src.dh * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int rowk = row0 + k * step + lr;
+                        const bool on = lane_on && rowk < uh;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)                         // (a quad may reach past the row: x < w)
+                            pull_add<DEPTH>(accv, accc, qx[k][j], qy[k][j], qd[k][j], px + j, uy0 + rowk, on && px + j < g.w, wbits, hbits,
+                                            ox0 - 1, oy0 - 1, sv, scn);
                     }
                 }
             }
@@ -463,26 +601,49 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         if (!attempt) st_t1 = __builtin_amdgcn_s_memtime();
 #endif
         __syncthreads();
-        // a cell = the grid cells of the top-left targets (x, y), (x - 1, y), (x, y - 1), (x - 1, y - 1): per grid
-        // row the horizontal pair once, shared by the two tile rows it feeds
+        // a cell = the grid cells of the top-left targets (x, y), (x - 1, y), (x, y - 1), (x - 1, y - 1): a lane
+        // reads the five grid cells above and the five beside its four cells
         int nmax = 0;
-        const unsigned long long xm = xlast ? ~0ull : 0ull;
-        const ccell xmc = xlast ? (ccell)~(ccell)0 : (ccell)0;
-        const int i0 = yl0 * PROJ_AW + lane;
-        unsigned long long hv = accv[i0] + accv[i0 + 1] + (accv[i0 + 1] & xm);
-        ccell hc = accc[i0] + accc[i0 + 1] + (accc[i0 + 1] & xmc);
 #pragma unroll
-        for (int r = 0; r < PROJ_ROWS; ++r) {
-            const int i1 = i0 + (r + 1) * PROJ_AW;
-            unsigned long long hv1 = accv[i1] + accv[i1 + 1] + (accv[i1 + 1] & xm);
-            ccell hc1 = accc[i1] + accc[i1 + 1] + (accc[i1 + 1] & xmc);
-            unsigned long long v = hv + hv1;
-            ccell c = hc + hc1;
-            if (oy0 + yl0 + r == g.h - 1) { v += hv1; c += hc1; }      // B == T there: the row adds twice
-            sumv[r] = v; sumc[r] = c;
-            hv = hv1; hc = hc1;
-            if (x < g.w && oy0 + yl0 + r < g.h) {
-                if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, (ccell)0x7fffffffu));
+        for (int it = 0; it < PROJ_EPI_ITERS; ++it) {
+            const int yl = it * 4 * PROJ_NW + wave * 4 + rw;
+            unsigned long long a[2][5];
+            ccell n[2][5];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* pv = reinterpret_cast<const uint4*>(accv + (yl + r) * PROJ_VS + 4 * q);
+                const uint4 v01 = pv[0], v23 = pv[1];
+                a[r][0] = v01.x | ((unsigned long long)v01.y << 32); a[r][1] = v01.z | ((unsigned long long)v01.w << 32);
+                a[r][2] = v23.x | ((unsigned long long)v23.y << 32); a[r][3] = v23.z | ((unsigned long long)v23.w << 32);
+                a[r][4] = accv[(yl + r) * PROJ_VS + 4 * q + 4];
+                if constexpr (DEPTH) {
+                    const uint4* pc = reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_VS + 4 * q);
+                    const uint4 c01 = pc[0], c23 = pc[1];
+                    n[r][0] = c01.x | ((unsigned long long)c01.y << 32); n[r][1] = c01.z | ((unsigned long long)c01.w << 32);
+                    n[r][2] = c23.x | ((unsigned long long)c23.y << 32); n[r][3] = c23.z | ((unsigned long long)c23.w << 32);
+                    n[r][4] = accc[(yl + r) * PROJ_VS + 4 * q + 4];
+                } else {
+                    const uint4 c03 = *reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_CS4 + 4 * q);
+                    n[r][0] = c03.x; n[r][1] = c03.y; n[r][2] = c03.z; n[r][3] = c03.w;
+                    n[r][4] = accc[(yl + r) * PROJ_CS4 + 4 * q + 4];
+                }
+            }
+            const bool ylast = oy0 + yl == g.h - 1;                        // B == T there: the row adds twice
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool xlast = xq + j == g.w - 1;                      // R == L there: the column adds twice
+                unsigned long long h0 = a[0][j] + a[0][j + 1], h1 = a[1][j] + a[1][j + 1];
+                ccell c0 = n[0][j] + n[0][j + 1], c1 = n[1][j] + n[1][j + 1];
+                if (xlast) { h0 += a[0][j + 1]; h1 += a[1][j + 1]; c0 += n[0][j + 1]; c1 += n[1][j + 1]; }
+                unsigned long long v = h0 + h1;
+                ccell c = c0 + c1;
+                if (ylast) { v += h1; c += c1; }
+                // exact integer sums -> float once
+                resx[it][j] = ldexpf((float)packed_hi(v), -kv); resy[it][j] = ldexpf((float)packed_lo(v), -kv);
+                if constexpr (DEPTH) resc[it][j] = ldexpf((float)packed_lo(c), -kc); else resc[it][j] = (float)c;
+                if (xq + j < g.w && oy0 + yl < g.h) {
+                    if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, (ccell)0x7fffffffu));
+                }
             }
         }
         if (attempt) break;
@@ -498,52 +659,81 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         for (int i = tid; i < ProjLds<DEPTH>::acc_bytes / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
-
 #ifdef PROJ_STAMPS
     st_t2 = __builtin_amdgcn_s_memtime();
 #endif
-    // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once; leave the two
+
+    // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once, 16 bytes per lane; leave the two
     // "count != 0" bitmaps for the hole filler and put the tile on its list if it has holes
-    unsigned mine = 0u;
     int holes = 0, negs = 0;
-    float* o = out + (int64_t)b * ob + (unsigned)((oy0 + yl0) * oh + x);
-    float* cnp = count + (int64_t)b * cb + (unsigned)((oy0 + yl0) * ch + x);
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)(count + (int64_t)b * cb), 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < PROJ_ROWS; ++r) {
-        const int yl = yl0 + r, y = oy0 + yl;
-        const bool inside = x < g.w && y < g.h;
-        // exact integer sums -> float once
-        float c;
-        if constexpr (DEPTH) c = ldexpf((float)packed_lo(sumc[r]), -kc); else c = (float)sumc[r];
-        float vx = ldexpf((float)packed_hi(sumv[r]), -kv), vy = ldexpf((float)packed_lo(sumv[r]), -kv);
-        if (c > 0.0f) { vx /= c; vy /= c; }
-        const bool nz = inside && c != 0.0f;
-        const unsigned long long rowbits = __ballot(nz);
-        if (lane < 2 && y < g.h && txi * 2 + lane < g.rmw)
-            bits[g.rowmap + (b * g.h + y) * g.rmw + txi * 2 + lane] = (int)(unsigned)(rowbits >> (32 * lane));
-        if (nz) mine |= 1u << yl;
-        holes += __popcll(__ballot(inside && c <= 0.0f));
-        if constexpr (DEPTH) negs += __popcll(__ballot(inside && c < 0.0f));
-        if (inside) {
-            o[(unsigned)(r * oh)] = vx;
-            o[oc + (unsigned)(r * oh)] = vy;
-            cnp[(unsigned)(r * ch)] = c;
+    for (int it = 0; it < PROJ_EPI_ITERS; ++it) {
+        const int yl = it * 4 * PROJ_NW + wave * 4 + rw, y = oy0 + yl;
+        float vxa[4], vya[4], ca[4];
+        unsigned nzb = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool inside = xq + j < g.w && y < g.h;
+            const float c = resc[it][j];
+            float vx = resx[it][j], vy = resy[it][j];
+            if (c > 0.0f) { vx /= c; vy /= c; }
+            vxa[j] = vx; vya[j] = vy; ca[j] = c;
+            if (inside && c != 0.0f) nzb |= 1u << j;
+            if (inside && c <= 0.0f) holes += 1;
+            if (DEPTH && inside && c < 0.0f) negs += 1;
+        }
+        if (nzb) atomicOr(&s_rowbits[yl * 2 + (q >> 3)], nzb << ((q & 7) * 4));
+#if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 2
+        if (y < g.h && kv == 12345) {
+#else
+        if (y < g.h) {
+#endif
+            const int so0 = (oy0 + it * 4 * PROJ_NW + wave * 4) * oh * 4, soc = (oy0 + it * 4 * PROJ_NW + wave * 4) * ch * 4;
+            const int vo = (rw * oh + xq) * 4, voc = (rw * ch + xq) * 4;
+            if (vec_ok && xq + 3 < g.w) {
+                const proj_v4i vx4 = {__float_as_int(vxa[0]), __float_as_int(vxa[1]), __float_as_int(vxa[2]), __float_as_int(vxa[3])};
+                const proj_v4i vy4 = {__float_as_int(vya[0]), __float_as_int(vya[1]), __float_as_int(vya[2]), __float_as_int(vya[3])};
+                const proj_v4i c4 = {__float_as_int(ca[0]), __float_as_int(ca[1]), __float_as_int(ca[2]), __float_as_int(ca[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(vx4, ro0, vo, so0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(vy4, ro1, vo, so0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(c4, rcn, voc, soc, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (xq + j < g.w) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(vxa[j]), ro0, vo + 4 * j, so0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(vya[j]), ro1, vo + 4 * j, so0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ca[j]), rcn, voc + 4 * j, soc, 0);
+                    }
+            }
         }
     }
-    if (mine) atomicOr(&s_colm[lane], mine);
-    if (lane == 0 && holes) atomicAdd(&s_misc[1], holes);
-    if (lane == 0 && negs) atomicAdd(&s_misc[2], negs);
+    if (holes) atomicAdd(&s_misc[1], holes);
+    if (negs) atomicAdd(&s_misc[2], negs);
     __syncthreads();
-    // a column word holds two tiles' rows: each tile stores its own 16-bit half (and the unused halves that
-    // pad a column line to whole 16-byte groups, if it is the last tile of the column)
+    // the row-packed bitmap: two words per tile row
+    if (tid < 2 * PROJ_TH) {
+        const int yl = tid >> 1, wi = txi * 2 + (tid & 1);
+        if (oy0 + yl < g.h && wi < g.rmw) bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + wi] = (int)s_rowbits[tid];
+    }
+    // the column-packed one: a column word holds two tiles' rows, each tile stores its own 16-bit half (and the
+    // unused halves that pad a column line to whole 16-byte groups, if it is the last tile of the column)
     if (tid < PROJ_TW && ox0 + tid < g.w) {
+        unsigned colbits = 0u;
+#pragma unroll
+        for (int r = 0; r < PROJ_TH; ++r) colbits |= ((s_rowbits[r * 2 + (tid >> 5)] >> (tid & 31)) & 1u) << r;
         unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + tid) * g.cmw) * 2;
-        half[tyi] = (unsigned short)s_colm[tid];
+        half[tyi] = (unsigned short)colbits;
         if (tyi == g.tiles_y - 1)
             for (int k = tyi + 1; k < 2 * g.cmw; ++k) half[k] = 0;
     }
-    // the list entry: the tile, flagged when it holds negative counts (non-zero, yet holes: K2 then reads the counts)
-    if (tid == 0 && s_misc[1]) ws[g.off_list + atomicAdd(&ws[PROJ_WS_NLIST], 1)] = tile | (s_misc[2] ? (int)0x80000000 : 0);
+    // the tile's word for K2: 0 = no holes, 1 = holes, 3 = holes and negative counts (non-zero, yet holes: K2 then
+    // reads the counts).  (A list of the tiles with holes, appended with one atomic per tile, costs ~12 ns per tile
+    // on its counter -- measured: 24 us more on a rough field where most tiles have holes.)
+    if (tid == 0) ws[g.off_list + tile] = s_misc[1] ? (s_misc[2] ? 3 : 1) : 0;
 #ifdef PROJ_STAMPS
     if (tid == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + g.off_list + g.ntiles + (g.ntiles & 1)) + (int64_t)tile * 8;
@@ -552,7 +742,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         st[0] = st_t0; st[1] = st_t1; st[2] = st_t2; st[3] = __builtin_amdgcn_s_memtime();
-        st[4] = st_r0; st[5] = __builtin_amdgcn_s_memrealtime(); st[6] = hwid; st[7] = xcc;
+        st[4] = st_r0; st[5] = __builtin_amdgcn_s_memrealtime(); st[6] = hwid; st[7] = (unsigned long long)xcc | ((st_ta - st_t0) << 8);
     }
 #endif
 }
@@ -608,20 +798,18 @@ __device__ __forceinline__ int mask_next(const unsigned long long* m, int j) {
 __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
     int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
-    // (the three words are loaded together: the list entry is read before the list's length is known)
     const bool fallback = ws[PROJ_WS_DIRTY] != 0;
-    const int nlist = ws[PROJ_WS_NLIST];
-    int entry = ws[g.off_list + (blockIdx.x < (unsigned)g.ntiles ? blockIdx.x : 0)];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;         // K0 of the next call starts afresh
-    if (!fallback && !fillhole) return;
+    // one workgroup per tile; K1 has left a word per tile: 0 = no holes (most tiles: the workgroup leaves at once),
+    // 1 = holes, 3 = holes and negative counts (non-zero, yet holes: the counts are read then)
+    const int tile = blockIdx.x;
+    const int tflag = ws[g.off_list + tile];
+    if (tile == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;               // K0 of the next call starts afresh
+    if (!fallback && (!fillhole || tflag == 0)) return;
     const int per_img = g.tiles_x * g.tiles_y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;            // wave = row of the tile
-    const int nwork = fallback ? g.ntiles : nlist;
     const bool generic = g.rmw > 64 * PROJ_LINE_CHUNKS || g.cmw > 64 * PROJ_LINE_CHUNKS;
-    for (int item = blockIdx.x; item < nwork; item += gridDim.x) {
-        if (item != (int)blockIdx.x) entry = ws[g.off_list + item];
-        const int tile = fallback ? item : (entry & 0x7fffffff);
-        const bool negatives = entry < 0;
+    {
+        const bool negatives = !fallback && (tflag & 2) != 0;
         const int b = tile / per_img;
         const int trem = tile - b * per_img;
         const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
@@ -631,7 +819,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
         float* o1 = o0 + s1.c;
         const int64_t row = (int64_t)y * s1.h;
         if (fallback) {
-            if (!inside) continue;
+            if (!inside) return;
             // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
             const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
             const float* p0 = planes + (int64_t)b * g.h * g.w;
@@ -643,7 +831,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
             if (c > 0.0f) {
                 o0[row + x] = p0[me] / c;
                 o1[row + x] = p1[me] / c;
-                continue;
+                return;
             }
             float v0 = 0.0f, v1 = 0.0f;
             if (fillhole) {
@@ -666,14 +854,14 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
             }
             o0[row + x] = v0;
             o1[row + x] = v1;
-            continue;
+            return;
         }
         const float* cn = count + (int64_t)b * sc.b;
         const int* rl = bits + g.rowmap + (b * g.h + min(y, g.h - 1)) * g.rmw;
         const int* cl = bits + g.colmap + (b * g.w + min(x, g.w - 1)) * g.cmw;
         int xl, xr, yu, yd;
         if (generic) {
-            if (!(inside && cn[(int64_t)y * sc.h + x] <= 0.0f)) continue;
+            if (!(inside && cn[(int64_t)y * sc.h + x] <= 0.0f)) return;
             xl = proj_bit_walk(rl, x, g.w, -1); xr = proj_bit_walk(rl, x, g.w, +1);
             yu = proj_bit_walk(cl, y, g.h, -1); yd = proj_bit_walk(cl, y, g.h, +1);
         } else {
@@ -716,7 +904,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
             }
             // a hole: its bit is clear -- or, in a tile that holds negative counts, its count is not positive
             const bool hole = inside && (negatives ? cme <= 0.0f : ((own >> jb) & 1u) == 0u);
-            if (!hole) continue;
+            if (!hole) return;
             const unsigned below = own & ((1u << jb) - 1u), above = jb == 31 ? 0u : own & ~((2u << jb) - 1u);
             xl = below ? j * 32 + 31 - __clz(below) : jl >= 0 ? jl * 32 + 31 - __clz(wl) : -1;
             xr = above ? j * 32 + __ffs((int)above) - 1 : jr >= 0 ? jr * 32 + __ffs((int)wr) - 1 : -1;
@@ -736,7 +924,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
         d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
         const float a0 = o0[row + l.pos], b0 = o0[row + rr.pos], c0 = o0[(int64_t)u.pos * s1.h + x], d0 = o0[(int64_t)d.pos * s1.h + x];
         const float a1 = o1[row + l.pos], b1 = o1[row + rr.pos], c1 = o1[(int64_t)u.pos * s1.h + x], d1 = o1[(int64_t)d.pos * s1.h + x];
-        if (l.cnt + rr.cnt + u.cnt + d.cnt <= 0.0f) continue;
+        if (l.cnt + rr.cnt + u.cnt + d.cnt <= 0.0f) return;
         const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
         const float rt = (rr.cnt > 0.0f) ? 1.0f : 0.0f;
         const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
@@ -853,14 +1041,30 @@ static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, fl
     src.fb = sf.b; src.fc = sf.c; src.db = DEPTH ? s2.b : 0;
     src.fh = (int)sf.h; src.dh = DEPTH ? (int)s2.h : 0;
     src.hq = hq; src.wq = wq; src.m0 = m0; src.m1 = m1;
-    hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
-                       (int64_t)z.plane_floats);
+    // 16-byte lanes need 16-byte aligned rows
+    const bool vec_in = !UP && (uintptr_t)flow % 16 == 0 && sf.b % 4 == 0 && sf.c % 4 == 0 && sf.h % 4 == 0 &&
+                        (!DEPTH || ((uintptr_t)in2 % 16 == 0 && s2.b % 4 == 0 && s2.h % 4 == 0));
+    if (vec_in) {
+        const int groups_x = (g.tiles_x + 3) / 4;
+        hipLaunchKernelGGL((proj_scan4<DEPTH>), dim3(batch * g.tiles_y * groups_x), dim3(256), 0, st, src, g, groups_x,
+                           p.words, p.planes, (int64_t)z.plane_floats);
+    } else {
+        hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
+                           (int64_t)z.plane_floats);
+    }
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
-    hipLaunchKernelGGL((proj_pull<DEPTH, UP>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
-                       (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, p.words, p.bits, p.planes);
+    // 16-byte stores need 16-byte aligned rows
+    const int vec_ok = ((uintptr_t)out % 16 == 0 && (uintptr_t)count % 16 == 0 && s1.b % 4 == 0 && s1.c % 4 == 0 && s1.h % 4 == 0 &&
+                        sc.b % 4 == 0 && sc.h % 4 == 0) ? 1 : 0;
+    if (vec_in)
+        hipLaunchKernelGGL((proj_pull<DEPTH, false, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes);
+    else
+        hipLaunchKernelGGL((proj_pull<DEPTH, UP, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
-    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles < 512 ? g.ntiles : 512), dim3(PROJ_FIN_THREADS), 0, st, count, out, g,
+    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_FIN_THREADS), 0, st, count, out, g,
                        s1, sc, p.words, p.bits, p.planes, fillhole);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return VFI_OK;
