@@ -1,38 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the frame-synthesis hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (starts its own N ranks when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json metric "interpolated frames/sec at 1080p", configs[2]): one STEP is
-the hot path of DAIN_slowmotion x4 for ONE 1080p frame pair (padded 1152x1984,
-demo_MiddleBury.py:294-310), i.e. exactly the native calls networks/DAIN_slowmotion.py:147-183
-and PWCNet/PWCNet.py:230-300 make for it:
+Workloads
+  slowmo1080 (default; BASELINE.json metric "interpolated frames/sec at 1080p", configs[2]): one STEP is the
+      hot path of DAIN_slowmotion x4 for ONE 1080p frame pair per GPU (padded 1152x1984,
+      demo_MiddleBury.py:294-310), i.e. exactly the native calls networks/DAIN_slowmotion.py:147-183 and
+      PWCNet/PWCNet.py:230-300 make for it:
+          10 x correlation forward   (5 pyramid levels x 2 directions; pad=4,k=1,md=4,s1=s2=1)
+           6 x DepthFlowProjection   (2 directions x t in {0.25,0.5,0.75}; fillhole=1)
+           6 x FilterInterpolation   on the 196-channel context tensor
+           6 x FilterInterpolation   on the 3-channel frame
+      and yields 3 interpolated frames.  Weak scaling: every rank has its own pair.
+  vimeo64 (BASELINE.json configs[3]): 64 Vimeo-90K triplets (256x448 padded to 320x512) through the DAIN x2 hot
+      path (per pair 10 correlation + 2 FlowProjection + 2 FilterInterpolation C=3, networks/DAIN.py:198-238), the
+      64 pairs sharded over the ranks with runner.shard_pairs; one STEP = every rank's shard once = 64 frames.
+      Strong scaling.
+The convolutional sub-networks around the path (PWC-Net convs, MegaDepth, context/rectify nets: stock MIOpen
+work) are outside this repo's scope and are NOT part of a step -- `value` is hot-path frames/s.
+All inputs are synthetic (vfidkr_amd/synthetic.py), float32, resident in HBM before timing.  Ranks share nothing:
+the only communication is the timing join (barrier, MAX of wall time, SUM of frames) over gloo.
 
-    10 x correlation forward   (5 pyramid levels x 2 directions; pad=4,k=1,md=4,s1=s2=1)
-     6 x DepthFlowProjection   (2 directions x t in {0.25,0.5,0.75}; fillhole=1)
-     6 x FilterInterpolation   on the 196-channel context tensor
-     6 x FilterInterpolation   on the 3-channel frame
-
-and yields 3 interpolated frames.  The convolutional sub-networks around it (PWC-Net convs,
-MegaDepth, context/rectify nets: stock MIOpen work) are outside this repo's scope and are
-NOT part of the step -- `value` is hot-path frames/s, not end-to-end model frames/s.
-All inputs are synthetic (vfidkr_amd/synthetic.py), float32, resident in HBM before timing.
-With N ranks every rank processes its own pair per step (weak scaling, no collective).
-
-Every native call goes through the C ABI of libvfi_hip.so (ctypes, vfidkr_amd/cabi.py).
-The JSON line also carries:
-  roofline      dominant kernel (FilterInterpolation, C=196): algorithmic bytes per launch
-                (1640 B/pixel x 2,285,568 pixels) / mean launch time measured with
-                HIP events on the launch stream inside the timed region, vs 8 TB/s
-  gate          north-star gate: 2 x FilterInterpolation(C=3) + 2 x FlowProjection at 1080p
-                (530 MB algorithmic) timed the same way
-  cpu_baseline  the CPU oracle (oracle/, a port: kind "port") timed on the host cores on a
-                bounded sample of the same workload, rank 0 at N=1 only
+Every native call goes through the C ABI of libvfi_hip.so (ctypes, vfidkr_amd/cabi.py).  The JSON line also carries
+  roofline          dominant kernel (FilterInterpolation, C=196): algorithmic bytes per launch (1640 B/pixel,
+                    SURVEY 8d) / mean launch time from HIP events on the launch stream INSIDE the timed region
+                    (each launch streams 3.6 GB: nothing of it is cache resident), vs 8 TB/s.  `traffic` = HBM
+                    bytes per launch from the rocprofv3 PMC passes committed under profiles/ for exactly this
+                    (frame size, flow model), else null.
+  roofline_quarter  the same launch on the SURVEY-8d-literal "quarter" flow field (measured after the timed region)
+  gate              north-star gate: 2 x FilterInterpolation(C=3) + 2 x FlowProjection at 1080p (530 MB
+                    algorithmic), `cold` = every call on a buffer set that has left the 256 MB Infinity Cache
+                    (rotation through > 512 MB of sets), `hot` = the same set every call
+  cpu_baseline      the CPU oracle (oracle/, a port: kind "port") timed on the host cores on a bounded sample
+                    of the same workload at 1 thread and at all cores, rank 0 at N=1 only
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,64 +48,154 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+L3_BYTES = 256 * 2 ** 20        # Infinity Cache
 TIMES = (0.25, 0.5, 0.75)       # x4 slow motion: numFrames = 3 (DAIN_slowmotion.py:29)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="slowmo1080", choices=["slowmo1080", "vimeo64"])
     ap.add_argument("--flow-model", default="smooth", choices=["smooth", "quarter", "uniform1"],
-                    help="synthetic flow field (vfidkr_amd/synthetic.py); 'quarter' = SURVEY 8d to the letter")
+                    help="synthetic flow field of the timed step (vfidkr_amd/synthetic.py); 'quarter' = SURVEY 8d to the letter")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cores)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (no gate / quarter / fp16 measurements)")
     ap.add_argument("--direct", action="store_true", help="force the direct-gather FilterInterpolation kernel")
-    return ap.parse_args()
+    ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
+                    help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
+    return ap.parse_args(argv)
 
 
-class Workload:
-    """All tensors of one frame pair, resident on `dev`."""
+# ------------------------------------------------------------------------------------------- workloads
+
+class SlowmoPair:
+    """All tensors of one 1080p frame pair of the DAIN_slowmotion x4 hot path, resident on `dev`."""
 
     def __init__(self, torch, S, dev, h, w, flow_model, seed):
         gen = S.generator(seed)
-        self.h, self.w = h, w
-        self.px = h * w
-        sigma = 8.0 * (w / 1984.0)
+        self.h, self.w, self.px = h, w, h * w
+        self.sigma = 8.0 * (w / 1984.0)
         self.frames = [S.frames(1, h, w, gen).to(dev) for _ in range(2)]
         self.ctx = [S.context(1, 196, h, w, gen).to(dev) for _ in range(2)]
         self.filters = [S.filters(1, h, w, gen).to(dev) for _ in range(2)]
         self.depth = [S.depth_weight(1, h, w, gen).to(dev) for _ in range(2)]
-        base = [S.flow(1, h, w, sigma, gen, flow_model) for _ in range(2)]
+        base = [S.flow(1, h, w, self.sigma, gen, flow_model) for _ in range(2)]
         # forward_flownets: one flow per time offset, scaled by t (DAIN_slowmotion.py:214-215)
         self.flows = [[(base[d] * (2.0 * t)).contiguous().to(dev) for t in TIMES] for d in range(2)]
         self.corr = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(1, h, w, gen)] for _ in range(2)]
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)      # noqa: E731
-        self.count = e(1, 1, h, w)
-        self.proj = e(1, 2, h, w)
-        self.out_ctx = e(1, 196, h, w)
-        self.out_img = e(1, 3, h, w)
-        self.host = dict(frame=self.frames[0].cpu(), filt=self.filters[0].cpu(), depth=self.depth[0].cpu(),
-                         flow=self.flows[0][1].cpu())
+        self.count, self.proj = e(1, 1, h, w), e(1, 2, h, w)
+        self.out_ctx, self.out_img = e(1, 196, h, w), e(1, 3, h, w)
+        self.gen = gen
 
 
-def main():
-    args = parse()
+class VimeoPair:
+    """One 256x448 triplet's tensors for the DAIN x2 hot path (padded 320x512)."""
+
+    def __init__(self, torch, S, dev, seed):
+        gen = S.generator(seed)
+        h, w = S.padded_size(256, 448)
+        self.h, self.w = h, w
+        self.frames = [S.frames(1, h, w, gen).to(dev) for _ in range(2)]
+        self.filters = [S.filters(1, h, w, gen).to(dev) for _ in range(2)]
+        self.flows = [(S.flow(1, h, w, 2.0, gen, "smooth") * 0.5).contiguous().to(dev) for _ in range(2)]   # time_offset 0.5
+        self.corr = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(1, h, w, gen)] for _ in range(2)]
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)      # noqa: E731
+        self.count, self.proj, self.out = e(1, 1, h, w), e(1, 2, h, w), [e(1, 3, h, w) for _ in range(2)]
+
+
+def hip_timed(torch, dev, fn, iters, nsets=1, warm=3):
+    """mean ms per call of fn(i % nsets) from HIP events on the current stream"""
+    for i in range(max(warm, nsets)):
+        fn(i % nsets)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for i in range(iters):
+        fn(i % nsets)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters
+
+
+# ------------------------------------------------------------------------------------------- one rank
+
+def run_rank(args):
     import torch
     import vfidkr_amd  # noqa: F401
-    from vfidkr_amd import cabi, runner, synthetic as S
+    from vfidkr_amd import runner
 
     rank, local_rank, world = runner.init_distributed()
+    if args.stub_step is not None:
+        return run_stub(args, runner, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    from vfidkr_amd import cabi, synthetic as S
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     cabi.lib()                                   # OSError here if libvfi_hip.so is missing
+    if args.workload == "vimeo64":
+        out = run_vimeo64(args, torch, cabi, runner, S, dev, rank, world)
+    else:
+        out = run_slowmo(args, torch, cabi, runner, S, dev, rank, world)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    runner.shutdown()
+    return 0
 
+
+def run_stub(args, runner, rank, world):
+    elapsed = runner.timed_region(lambda i: time.sleep(args.stub_step), args.steps)
+    total = runner.total_units(args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/s (launcher plumbing test, no GPU work)", "value": round(total / elapsed, 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub", "config": {"workload": "stub"}}), flush=True)
+    runner.shutdown()
+    return 0
+
+
+def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
+    n_pairs = 64
+    mine = list(runner.shard_pairs(n_pairs, rank, world))
+    pairs = [VimeoPair(torch, S, dev, S.SEED + 1000 + i) for i in mine]
+
+    def step(_i):
+        for p in pairs:                                     # B = 1 per call (PWC-Net's warp allows B <= 3, PWCNet.py:144)
+            for d in range(2):
+                for a, b in p.corr[d]:
+                    cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+            for d in range(2):                              # DAIN.FlowProject + DAIN.FilterInterpolate (DAIN.py:218-238)
+                assert cabi.flowprojection_forward(p.flows[d], p.count, p.proj, 1) == 0
+                assert cabi.filterinterp_forward_ori(p.frames[d], p.proj, p.filters[d], p.out[d]) == 0
+
+    for i in range(args.warmup):
+        step(i)
+    elapsed = runner.timed_region(step, args.steps, dev)
+    frames_total = runner.total_units(len(mine) * args.steps)
+    h, w = pairs[0].h, pairs[0].w
+    return {
+        "metric": "interpolated frames/sec, 64 Vimeo-90K triplets (hot path only: correlation + FlowProjection + "
+                  "FilterInterpolation of DAIN x2)",
+        "value": round(frames_total / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "vimeo64: 64 triplets 256x448 padded to %dx%d, DAIN x2 hot path per pair (10 correlation + "
+                               "2 FlowProjection(fillhole) + 2 FilterInterpolation(C=3)), B=1 per call; 1 frame per pair"
+                               % (h, w),
+                   "pairs": n_pairs, "pairs_per_rank": [len(runner.shard_pairs(n_pairs, r, world)) for r in range(world)],
+                   "filter_size": 4, "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
+    }
+
+
+def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     h, w = S.padded_size(args.height, args.width)
-    wl = Workload(torch, S, dev, h, w, args.flow_model, S.SEED + rank)
+    wl = SlowmoPair(torch, S, dev, h, w, args.flow_model, S.SEED + rank)
     px = wl.px
     fi196_events = []
 
@@ -125,26 +222,16 @@ def main():
     for i in range(args.warmup):
         step(i)
     elapsed = runner.timed_region(lambda i: step(i, record=True), args.steps, dev)
-    frames_total = runner.total_units(len(TIMES) * args.steps, dev)
+    frames_total = runner.total_units(len(TIMES) * args.steps)
     value = frames_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel, from HIP events recorded inside the timed region
     torch.cuda.synchronize(dev)
     fi196_ms = sum(a.elapsed_time(b) for a, b in fi196_events) / max(1, len(fi196_events))
-    fi196_bytes = 1640.0 * px
-    achieved = fi196_bytes / (fi196_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "fi196_traffic.json")
-    if os.path.exists(tpath) and not args.direct and args.flow_model == "smooth":
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("hbm_bytes_per_launch")     # rocprofv3 --pmc passes, see profiles/README.md
-    roofline = {"kernel": "fi_forward_ori_lds (FilterInterpolation _ori forward, C=196, fs=4)"
-                if not args.direct else "fi_forward_ori_direct<true> (C=196)",
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": fi196_bytes, "avg_launch_ms": round(fi196_ms, 4),
-                "launches_timed": len(fi196_events)}
+    kernel = ("fi_forward_ori_lds (FilterInterpolation _ori forward, C=196, fs=4)" if not args.direct
+              else "fi_forward_ori_direct<true> (C=196)")
+    roofline = roofline_block(kernel, px, fi196_ms, len(fi196_events), traffic_lookup(h, w, args.flow_model, args.direct))
 
     out = {
         "metric": "interpolated frames/sec at 1080p (hot path only: correlation + DepthFlowProjection + "
@@ -160,75 +247,100 @@ def main():
                    "parallelism": "replicas x%d (one pair per GPU, no collective)" % world},
         "roofline": roofline,
     }
-
-    if rank == 0:
-        out["gate"] = gate_measurement(torch, cabi, wl, dev, args)
+    if rank == 0 and not args.no_extras:
+        if args.flow_model != "quarter":
+            out["roofline_quarter"] = quarter_measurement(torch, cabi, S, wl, dev, args, kernel)
+        out["gate"] = gate_measurement(torch, cabi, S, wl, dev, args)
         out["fp16_storage"] = fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cabi, wl, dev, args)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    return out
 
 
-def gate_measurement(torch, cabi, wl, dev, args, iters=50):
-    """North-star gate: 2 x FilterInterpolation(C=3) + 2 x FlowProjection at 1080p, kernel time by
-    HIP events on the launch stream; algorithmic bytes 96 B/px and 20 B/px."""
-    px = wl.px
+def roofline_block(kernel, px, ms, launches, traffic):
+    nbytes = 1640.0 * px
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_ms": round(ms, 4), "launches_timed": launches}
 
-    def timed(fn, n=iters):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / n
 
-    flow = wl.flows[0][1]
+def traffic_lookup(h, w, flow_model, direct):
+    """HBM bytes per C=196 launch from the committed rocprofv3 PMC passes -- only for the exact (frame size, flow
+    model, kernel) they were collected on (profiles/README.md says how); anything else has no counter evidence: null."""
+    path = os.path.join(ROOT, "profiles", "traffic_by_config.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        for e in json.load(fh).get("entries", []):
+            if (e.get("h"), e.get("w"), e.get("flow_model"), bool(e.get("direct"))) == (h, w, flow_model, bool(direct)):
+                return e.get("hbm_bytes_per_launch")
+    return None
 
-    def fi3():
-        assert cabi.filterinterp_forward_ori(wl.frames[0], flow, wl.filters[0], wl.out_img, direct=args.direct) == 0
 
-    def fp_as_called():
-        assert cabi.flowprojection_forward(flow, wl.count, wl.proj, 1) == 0
+def quarter_measurement(torch, cabi, S, wl, dev, args, kernel, iters=12):
+    """The dominant launch on SURVEY 8d's literal flow field: bilinear x4 of N(0, sigma^2) drawn at quarter resolution."""
+    flow = (S.flow(1, wl.h, wl.w, wl.sigma, wl.gen, "quarter") * 1.0).to(dev)       # t = 0.5: the middle offset
+    cnt, proj = torch.empty_like(wl.count), torch.empty_like(wl.proj)
+    assert cabi.depthflowprojection_forward(flow, wl.depth[0], cnt, proj, 1) == 0
 
-    fi3_ms = timed(fi3)
-    fp_ms = timed(fp_as_called)
-    total_ms = 2 * fi3_ms + 2 * fp_ms
+    def run(i):
+        assert cabi.filterinterp_forward_ori(wl.ctx[i % 2], proj, wl.filters[0], wl.out_ctx, direct=args.direct) == 0
+    ms = hip_timed(torch, dev, run, iters, nsets=2)
+    r = roofline_block(kernel, wl.px, ms, iters, traffic_lookup(wl.h, wl.w, "quarter", args.direct))
+    r["flow_model"] = "quarter"
+    return r
+
+
+def gate_measurement(torch, cabi, S, wl, dev, args, iters=60):
+    """North-star gate: 2 x FilterInterpolation(C=3) + 2 x FlowProjection at 1080p; kernel time by HIP events on the
+    launch stream; algorithmic bytes 96 B/px and 20 B/px.  cold: every call works on a set of buffers
+    that was last touched > 512 MB of traffic ago; hot: the same set every call."""
+    px, h, w = wl.px, wl.h, wl.w
+    n_fi = int(2 * L3_BYTES / (96.0 * px)) + 2
+    n_fp = int(2 * L3_BYTES / (20.0 * px)) + 2
+    fi_sets = [(S.frames(1, h, w, wl.gen).to(dev), wl.flows[0][1].clone(), S.filters(1, h, w, wl.gen).to(dev),
+                torch.empty((1, 3, h, w), device=dev)) for _ in range(n_fi)]
+    fp_sets = [(wl.flows[0][1].clone(), torch.empty((1, 1, h, w), device=dev), torch.empty((1, 2, h, w), device=dev))
+               for _ in range(n_fp)]
+
+    def fi3(i):
+        img, flow, filt, out = fi_sets[i]
+        assert cabi.filterinterp_forward_ori(img, flow, filt, out, direct=args.direct) == 0
+
+    def fp(i):
+        flow, cnt, out = fp_sets[i]
+        assert cabi.flowprojection_forward(flow, cnt, out, 1) == 0
+
+    res = {"what": "2 x FilterInterpolation(C=3) + 2 x FlowProjection(fillhole; all its launches), %dx%d, flow model %s"
+                   % (h, w, args.flow_model), "target_frac": 0.5,
+           "rotation": "%d FilterInterpolation sets (%.0f MB each), %d FlowProjection sets (%.0f MB each)"
+                       % (n_fi, 96.0 * px / 1e6, n_fp, 20.0 * px / 1e6)}
     gbytes = (2 * 96.0 + 2 * 20.0) * px / 1e9
-    return {"what": "2 x FilterInterpolation(C=3) + 2 x FlowProjection(fillhole; all its launches), %dx%d"
-                    % (wl.h, wl.w),
-            "fi_c3_ms": round(fi3_ms, 4), "fi_c3_GBps": round(96.0 * px / fi3_ms / 1e6, 1),
-            "flowproj_ms": round(fp_ms, 4), "flowproj_GBps": round(20.0 * px / fp_ms / 1e6, 1),
-            "total_ms": round(total_ms, 4), "algorithmic_GB": round(gbytes, 4),
-            "achieved_GBps": round(gbytes / (total_ms * 1e-3), 1),
-            "frac_of_8TBps": round(gbytes / (total_ms * 1e-3) / HBM_PEAK_GBS, 4), "target_frac": 0.5}
+    for name, nf, np_ in (("cold", n_fi, n_fp), ("hot", 1, 1)):
+        fi3_ms = hip_timed(torch, dev, fi3, iters, nf)
+        fp_ms = hip_timed(torch, dev, fp, iters, np_)
+        total_ms = 2 * fi3_ms + 2 * fp_ms
+        res[name] = {"fi_c3_ms": round(fi3_ms, 4), "fi_c3_GBps": round(96.0 * px / fi3_ms / 1e6, 1),
+                     "flowproj_ms": round(fp_ms, 4), "flowproj_GBps": round(20.0 * px / fp_ms / 1e6, 1),
+                     "total_ms": round(total_ms, 4), "achieved_GBps": round(gbytes / (total_ms * 1e-3), 1),
+                     "frac_of_8TBps": round(gbytes / (total_ms * 1e-3) / HBM_PEAK_GBS, 4)}
+    res["algorithmic_GB"] = round(gbytes, 4)
+    res["frac_of_8TBps"] = res["cold"]["frac_of_8TBps"]             # the figure that counts: nothing cache resident
+    return res
 
 
-def fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step, iters=20):
+def fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step, iters=12):
     """BASELINE.json configs[2] names "fp16 storage / fp32 accum": the dominant launch with the context
     tensor and its output stored as fp16 (856 B/px algorithmic).  Reported beside the fp32
     headline, never as `value`."""
-    ctx16 = wl.ctx[0].to(torch.float16)
-    out16 = torch.empty_like(ctx16)
+    ctx16 = [c.to(torch.float16) for c in wl.ctx]
+    out16 = torch.empty_like(ctx16[0])
     flow, filt = wl.flows[0][1], wl.filters[0]
 
-    def run():
-        assert cabi.filterinterp_forward_ori_f16(ctx16, flow, filt, out16) == 0
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / iters
+    def run(i):
+        assert cabi.filterinterp_forward_ori_f16(ctx16[i % 2], flow, filt, out16) == 0
+    ms = hip_timed(torch, dev, run, iters, nsets=2)
     gbs = 856.0 * wl.px / ms / 1e6
     step_ms = ms_per_step - 6.0 * (fi196_ms - ms)
     return {"kernel": "fi_forward_ori_lds_f16 (C=196, image and output fp16, flow / filter / arithmetic fp32)",
@@ -237,56 +349,57 @@ def fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step, iters=
 
 
 def cpu_baseline(torch, cabi, wl, dev, args):
-    """Times the CPU oracle (a port of the reference's arithmetic; the reference has no CPU path)
-    on a bounded sample and scales it to one step; also reports parity of the GPU result on it."""
+    """Times the CPU oracle (a port of the reference's arithmetic; the reference has no CPU path) on a bounded
+    sample of one step -- at 1 thread and at every host core, median of 5 runs each -- and scales it to a step;
+    also reports the parity of the GPU result on that sample.  Sample: one (direction, t) unit with the context
+    tensor cut to 16 of its 196 channels (FilterInterpolation's cost is linear in channels, the flow / filter
+    part is in the C=3 call's measurement), and the 5-level correlation of one direction."""
     import numpy as np
     from oracle import cpu_oracle as oracle
-    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-    oracle.set_num_threads(threads)
-    hst = wl.host
-    frame, filt, depth, flow = (hst[k].numpy() for k in ("frame", "filt", "depth", "flow"))
-    ctx_full = wl.ctx[0].cpu().numpy()
-    csel = 16                                   # channels kept for the parity check below
-
-    # one (direction, t) unit of the step at full size: 1/6 of the projection + warping work
-    t0 = time.perf_counter()
+    ncpu = os.cpu_count() or 1
+    csel = 16
+    frame, filt = wl.frames[0].cpu().numpy(), wl.filters[0].cpu().numpy()
+    depth, flow = wl.depth[0].cpu().numpy(), wl.flows[0][1].cpu().numpy()
+    ctx_sel = np.ascontiguousarray(wl.ctx[0][:, :csel].cpu().numpy())
+    corr_np = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in wl.corr[0]]
     proj, _ = oracle.depthflowproj_fwd(flow, depth, 1)
-    t_dfp = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ref_full = oracle.filterinterp_ori_fwd(ctx_full, proj, filt, fmad=1, nthreads=threads)
-    t_fi196 = time.perf_counter() - t0
-    ref_ctx = ref_full[:, :csel].copy()
-    del ref_full, ctx_full
-    t0 = time.perf_counter()
-    ref_img = oracle.filterinterp_ori_fwd(frame, proj, filt, fmad=1, nthreads=threads)
-    t_fi3 = time.perf_counter() - t0
-    # the 5-level correlation of one direction: 1/2 of the correlation work
-    t0 = time.perf_counter()
-    corr_ref = None
-    for a, b in wl.corr[0]:
-        corr_ref = oracle.correlation_fwd(a.cpu().numpy(), b.cpu().numpy(), 4, 1, 4, 1, 1, order=0)
-    t_corr = time.perf_counter() - t0
-    # repeat the dominant call until the sample holds ~10 s of CPU work (threads x wall)
-    reps = 0
-    while (t_dfp + t_fi196 * (1 + reps) + t_fi3 + t_corr) * threads < 10.0 and reps < 5:
-        t0 = time.perf_counter()
-        oracle.filterinterp_ori_fwd(wl.ctx[1].cpu().numpy(), proj, filt, fmad=1, nthreads=threads)
-        t_fi196 = min(t_fi196, time.perf_counter() - t0)
-        reps += 1
-    step_s = 6 * (t_dfp + t_fi196 + t_fi3) + 2 * t_corr
-    base = {"value": round(len(TIMES) / step_s, 5), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "oracle/vfi_oracle.c (C restatement; the reference has no CPU path) at %dx%d on %d threads: "
-                      "1 DepthFlowProjection (%.3fs, sequential scatter), 1 FilterInterpolation C=196 (%.3fs, best of "
-                      "%d), 1 FilterInterpolation C=3 (%.3fs), 5-level correlation of one direction (%.3fs); "
-                      "step = 6 x (proj + FI196 + FI3) + 2 x corr = %.2fs"
-                      % (wl.h, wl.w, threads, t_dfp, t_fi196, reps + 1, t_fi3, t_corr, step_s)}
+
+    def med(fn, n=5):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), r
+
+    def one_config(threads):
+        oracle.set_num_threads(threads)
+        t_dfp, _ = med(lambda: oracle.depthflowproj_fwd(flow, depth, 1))            # sequential scatter: one thread whatever `threads`
+        t_fi3, ref_img = med(lambda: oracle.filterinterp_ori_fwd(frame, proj, filt, fmad=1, nthreads=threads))
+        t_fic, ref_ctx = med(lambda: oracle.filterinterp_ori_fwd(ctx_sel, proj, filt, fmad=1, nthreads=threads))
+        t_corr, corr_ref = med(lambda: [oracle.correlation_fwd(a, b, 4, 1, 4, 1, 1, order=0) for a, b in corr_np][-1])
+        # channels scale the per-channel part of the C=16 call: t(C) = t_fixed + C * t_channel, from the C=3 and C=16 runs
+        per_ch = max(0.0, (t_fic - t_fi3) / float(csel - 3))
+        t_fi196 = t_fi3 + per_ch * (196 - 3)
+        step_s = 6 * (t_dfp + t_fi196 + t_fi3) + 2 * t_corr
+        return dict(threads=threads, dfp=t_dfp, fi3=t_fi3, fi16=t_fic, fi196=t_fi196, corr=t_corr, step=step_s), ref_img, ref_ctx, corr_ref
+
+    c1, _, _, _ = one_config(1)
+    cn, ref_img, ref_ctx, corr_ref = one_config(ncpu)
+    base = {"value": round(len(TIMES) / cn["step"], 5), "unit": "frames/s", "cores": ncpu, "kind": "port",
+            "value_1_thread": round(len(TIMES) / c1["step"], 5),
+            "sample": "oracle/vfi_oracle.c (C restatement; the reference has no CPU path) at %dx%d, median of 5 runs per call, "
+                      "at 1 thread / %d threads: DepthFlowProjection %.3f / %.3f s (sequential scatter), FilterInterpolation "
+                      "C=3 %.3f / %.3f s, C=16 %.3f / %.3f s -> C=196 extrapolated linearly in channels %.2f / %.2f s, "
+                      "5-level correlation of one direction %.3f / %.3f s; step = 6 x (proj + FI196 + FI3) + 2 x corr = "
+                      "%.1f / %.2f s"
+                      % (wl.h, wl.w, ncpu, c1["dfp"], cn["dfp"], c1["fi3"], cn["fi3"], c1["fi16"], cn["fi16"], c1["fi196"],
+                         cn["fi196"], c1["corr"], cn["corr"], c1["step"], cn["step"])}
 
     # parity of the GPU path on the same sample (GPU fed the oracle's projected flow -> exact compare)
     gproj = torch.tensor(proj, device=dev)
     out = torch.empty((1, csel, wl.h, wl.w), dtype=torch.float32, device=dev)
-    ctx_sel = torch.empty_like(out)                 # fresh dense strides (a channel slice keeps the 196-channel batch stride)
-    ctx_sel.copy_(wl.ctx[0][:, :csel])
-    assert cabi.filterinterp_forward_ori(ctx_sel, gproj, wl.filters[0], out, direct=args.direct) == 0
+    assert cabi.filterinterp_forward_ori(torch.tensor(ctx_sel, device=dev), gproj, wl.filters[0], out, direct=args.direct) == 0
     out3 = torch.empty_like(wl.frames[0])
     assert cabi.filterinterp_forward_ori(wl.frames[0], gproj, wl.filters[0], out3, direct=args.direct) == 0
     cnt = torch.empty_like(wl.count)
@@ -309,5 +422,23 @@ def cpu_baseline(torch, cabi, wl, dev, args):
     return base, parity
 
 
+# ------------------------------------------------------------------------------------------- launcher
+
+def main(argv=None):
+    args = parse(argv)
+    from vfidkr_amd import runner
+    if args.gpus > 1 and not runner.launched_externally():
+        # start the ranks ourselves, before anything here has touched a GPU (device_count does not initialise HIP)
+        if args.stub_step is None:
+            import torch
+            n = torch.cuda.device_count()
+            if n < args.gpus:
+                print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, n), file=sys.stderr)
+                return 2
+        child = [os.path.abspath(__file__)] + (list(argv) if argv is not None else sys.argv[1:])
+        return runner.spawn_ranks(child, args.gpus)
+    return run_rank(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

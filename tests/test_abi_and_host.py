@@ -50,6 +50,19 @@ def test_library_exports_every_declared_symbol(built):
     assert (oc.value, oh.value, ow.value) == (441, 5, 6)
 
 
+def test_product_library_exports_no_development_knobs(built):
+    """Kernel-selection knobs exist only in -DVFI_DEV builds: the product exports the declared ABI, the internal
+    single-path entry points the tests and tools time, and nothing that mutates process-global state."""
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("vfi_")}
+    from vfidkr_amd import cabi
+    declared = set(header_functions())
+    extra = exported - declared - set(cabi.INTERNAL_SIGNATURES)
+    assert not any(n.startswith(("vfi_debug", "vfi_dev")) for n in exported), sorted(exported)
+    # what is left are the per-path entry points (e.g. vfi_filterinterp_forward_ori_lds) the public ones dispatch to
+    assert all(("_lds" in n or "_direct" in n or "_general" in n) for n in extra), sorted(extra)
+
+
 def test_ctypes_table_matches_header(built):
     from vfidkr_amd import cabi
     declared = set(header_functions()) - {"vfi_version"}
@@ -187,6 +200,37 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res["total"] == 13.0
     assert sorted(res["parts"][0] + res["parts"][1]) == list(range(13))
     assert res["t"] >= 3 * 0.02 * 0.9            # rank 1 sleeps 0.02 s per step: MAX, not rank 0's 0.03 s
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no RANK in the environment starts two ranks itself (gloo timing join) and prints ONE
+    JSON line whose n_gpus is the number of ranks that ran; --stub-step replaces the GPU step by a sleep."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0",
+                        "--stub-step", "0.02"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["data"] == "stub"
+    assert res["ms_per_step"] >= 20.0 * 0.9
+
+
+def test_bench_launcher_fails_cleanly_without_gpus():
+    """on a box with fewer GPUs than --gpus the parent says so and exits non-zero before starting anything;
+    a rank that dies makes the parent exit non-zero too."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import runner
+    rc = runner.spawn_ranks(["-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], 2, timeout=60)
+    assert rc == 3
 
 
 # ------------------------------------------------------------------ a compiler hazard of the LDS-DMA pipelines

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import vfidkr_amd  # noqa: E402,F401
+if "--lib" in sys.argv:         # a development build of the library (make OUT=../lib_dev EXTRA=-DVFI_DEV): needed by --knobs
+    vfidkr_amd.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from vfidkr_amd import cabi, synthetic as S  # noqa: E402
 
 
@@ -34,7 +36,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--knobs", default="", help="comma list of flags:groups pairs for vfi_debug_filterinterp, e.g. 0:0,1:0,0:1")
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--knobs", default="", help="comma list of flags:groups pairs for vfi_dev_filterinterp, e.g. 0:0,1:0,0:1")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     h, w = S.padded_size(args.height, args.width)
@@ -54,12 +57,12 @@ def main():
             timed(lambda: cabi.filterinterp_forward_ori(ctx, flow, filt, out196), args.iters)
         for knob in [k for k in args.knobs.split(",") if k]:
             fl, gr = (int(v, 0) for v in knob.split(":"))
-            cabi.lib().vfi_debug_filterinterp(fl, gr)
+            cabi.lib().vfi_dev_filterinterp(fl, gr)
             ms = timed(lambda: cabi.filterinterp_forward_ori(ctx, flow, filt, out196), args.iters)
             ms3 = timed(lambda: cabi.filterinterp_forward_ori(frame, flow, filt, out3), args.iters * 5)
             print("knob flags=%#x groups=%d %-8s fi196 %8.4f ms %7.1f GB/s | fi3 %8.4f ms %7.1f GB/s"
                   % (fl, gr, model, ms, 1640.0 * px / ms / 1e6, ms3, 96.0 * px / ms3 / 1e6), flush=True)
-            cabi.lib().vfi_debug_filterinterp(0, 0)
+            cabi.lib().vfi_dev_filterinterp(0, 0)
         for direct in (False, True):
             tag = "direct" if direct else "lds"
             if "fi196" in ops:
@@ -88,32 +91,26 @@ def main():
         if "dproj" in ops:
             ms = timed(dfp, args.iters * 2)
             print("dproj %-8s        %8.4f ms %8.1f GB/s (all launches)" % (model, ms, 24.0 * px / ms / 1e6), flush=True)
+    # correlation kernel-selection experiments: need a development build of the library (--lib, make EXTRA=-DVFI_DEV)
+    def corr_knobs(big, flat, rows2):
+        import ctypes
+        fn = cabi.lib().vfi_dev_correlation
+        fn.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
+        fn(big, flat, rows2)
+
+    def corr_sweep(tag):
+        for a, b in S.correlation_features(1, h, w, S.generator()):
+            a, b = a.to(dev), b.to(dev)
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            print("corr %-28s C=%-3d %4dx%-4d %8.4f ms" % (tag, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
     for fthr in ([0, 64, 256, 1024] if "corrflat" in ops else []):
-        cabi.lib().vfi_debug_correlation_flat.argtypes = [__import__("ctypes").c_longlong]
-        cabi.lib().vfi_debug_correlation_flat(fthr)
-        for a, b in S.correlation_features(1, h, w, S.generator()):
-            a, b = a.to(dev), b.to(dev)
-            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
-            print("corr flat<%-5d C=%-3d %4dx%-4d %8.4f ms" % (fthr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
-        cabi.lib().vfi_debug_correlation_flat(64)
+        corr_knobs(256, fthr, 1)
+        corr_sweep("flat<%d" % fthr)
     for r2, thr in ([(1, 256), (1, 1 << 40), (0, 256), (0, 1 << 40)] if "corrrows2" in ops else []):
-        cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
-        cabi.lib().vfi_debug_correlation(thr)
-        cabi.lib().vfi_debug_correlation_rows2(r2)
-        for a, b in S.correlation_features(1, h, w, S.generator()):
-            a, b = a.to(dev), b.to(dev)
-            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
-            print("corr rows2=%d big>=%-14d C=%-3d %4dx%-4d %8.4f ms" % (r2, thr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
-        cabi.lib().vfi_debug_correlation(256)
-        cabi.lib().vfi_debug_correlation_rows2(1)
-    for thr in ([256, 1 << 40, 0] if "corrknob" in ops else []):
-        cabi.lib().vfi_debug_correlation.argtypes = [__import__("ctypes").c_longlong]
-        cabi.lib().vfi_debug_correlation(thr)
-        for a, b in S.correlation_features(1, h, w, S.generator()):
-            a, b = a.to(dev), b.to(dev)
-            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
-            print("corr thr=%-14d C=%-3d %4dx%-4d %8.4f ms" % (thr, a.shape[1], a.shape[2], a.shape[3], ms), flush=True)
-        cabi.lib().vfi_debug_correlation(256)
+        corr_knobs(thr, 64, r2)
+        corr_sweep("rows2=%d big>=%d" % (r2, thr))
+    if "corrflat" in ops or "corrrows2" in ops:
+        corr_knobs(256, 64, 1)
     if "glue" in ops:
         # the steps either side of the ops: fused launch vs the torch ops the reference uses
         import torch.nn.functional as F

@@ -18,7 +18,7 @@ def timed(fn, n=20):
     return a.elapsed_time(b) / n
 timed(lambda: cabi.filterinterp_forward_ori(full, flow, filt, torch.empty_like(full)))
 for groups in (1, 2):
-    cabi.lib().vfi_debug_filterinterp(0, groups)
+    cabi.lib().vfi_dev_filterinterp(0, groups)
     for C in (12, 24, 49, 98, 196):
         x = full[:, :C].contiguous(); o = torch.empty_like(x)
         ms = timed(lambda: cabi.filterinterp_forward_ori(x, flow, filt, o))

@@ -9,13 +9,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import vfidkr_amd  # noqa: E402,F401
+if "--lib" in sys.argv:         # a development build of the library (make OUT=../lib_dev EXTRA=-DVFI_DEV) for the knobs
+    i = sys.argv.index("--lib")
+    vfidkr_amd.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 from vfidkr_amd import cabi, synthetic as S  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "smooth"
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 196
 if len(sys.argv) > 3:        # development knobs of the LDS kernel (flags[:groups])
     fl = sys.argv[3].split(":")
-    cabi.lib().vfi_debug_filterinterp(int(fl[0], 0), int(fl[1], 0) if len(fl) > 1 else 0)
+    cabi.lib().vfi_dev_filterinterp(int(fl[0], 0), int(fl[1], 0) if len(fl) > 1 else 0)
 dev = torch.device("cuda:0")
 h, w = S.padded_size(1080, 1920)
 gen = S.generator()

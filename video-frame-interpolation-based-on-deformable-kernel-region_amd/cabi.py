@@ -71,6 +71,8 @@ SIGNATURES = {
 INTERNAL_SIGNATURES = {
     "vfi_filterinterp_forward_ori_direct": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_forward_ori_f16_direct": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_forward_defor_general": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
+                                               Strides, _p],
 }
 
 _lib = None
@@ -174,8 +176,9 @@ def filterinterp_backward_ori(input1, input2, input3, gradoutput, gradinput1, gr
             _ptr(gradinput3), b, c, h, w, input3.size(1), _st(input1), _st(input2), _st(input3), _stream(input1)))
 
 
-def filterinterp_forward_defor(variant, input1, input2, input3, input4, output):
-    """variant: DEFOR_OFFSET (4-input forward), DEFOR_REGION (deforconv), DEFOR_NOFILTER (input4 = None)."""
+def filterinterp_forward_defor(variant, input1, input2, input3, input4, output, general=False):
+    """variant: DEFOR_OFFSET (4-input forward), DEFOR_REGION (deforconv), DEFOR_NOFILTER (input4 = None).
+    general=True: always the one-thread-per-pixel kernel (an internal entry point the tests compare the staged one with)."""
     dims = _fi_checks(input1, input2, input3, output if variant == DEFOR_NOFILTER else None)
     if dims is None:
         return 1
@@ -189,9 +192,9 @@ def filterinterp_forward_defor(variant, input1, input2, input3, input4, output):
         fs = int(math.sqrt(input3.size(1)))
         p4, s4 = _ptr(input4), _st(input4)
     with torch.cuda.device(_dev(input1)):
-        return _finish(lib().vfi_filterinterp_forward_defor(
-            variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(output), b, c, h, w, fs, _st(input1),
-            _st(input2), _st(input3), s4, _stream(input1)))
+        fn = lib().vfi_filterinterp_forward_defor_general if general else lib().vfi_filterinterp_forward_defor
+        return _finish(fn(variant, _ptr(input1), _ptr(input2), _ptr(input3), p4, _ptr(output), b, c, h, w, fs, _st(input1),
+                          _st(input2), _st(input3), s4, _stream(input1)))
 
 
 def filterinterp_backward_defor(variant, input1, input2, input3, input4, gradoutput, gradinput1, gradinput2,

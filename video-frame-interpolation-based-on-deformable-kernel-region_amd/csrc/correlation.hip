@@ -498,14 +498,17 @@ __global__ __launch_bounds__(256) void corr_backward(
 
 using namespace vfi;
 
-// development knob: number of 32x8 tiles from which the one-lane-per-pixel kernel is used
-static long long g_corr_big_threshold = 256;
+// kernel selection thresholds (development knobs, see vfi_common.h): number of 32x8 tiles from which the
+// one-lane-per-pixel kernel is used ...
+VFI_KNOB(long long, g_corr_big_threshold, 256);
 // ... and number of 16x4 tiles below which the one-thread-per-output kernel is used
-static long long g_corr_flat_threshold = 64;    // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
-extern "C" void vfi_debug_correlation(long long big_threshold) { g_corr_big_threshold = big_threshold; }
-extern "C" void vfi_debug_correlation_flat(long long flat_threshold) { g_corr_flat_threshold = flat_threshold; }
-static int g_corr_rows2 = 1;        // two pixels per lane in the tiled kernel
-extern "C" void vfi_debug_correlation_rows2(int on) { g_corr_rows2 = on; }
+VFI_KNOB(long long, g_corr_flat_threshold, 64);     // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
+VFI_KNOB(int, g_corr_rows2, 1);                     // two pixels per lane in the tiled kernel
+#ifdef VFI_DEV
+extern "C" void vfi_dev_correlation(long long big_threshold, long long flat_threshold, int rows2) {
+    g_corr_big_threshold = big_threshold; g_corr_flat_threshold = flat_threshold; g_corr_rows2 = rows2;
+}
+#endif
 
 extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
                                             int stride1, int stride2, int* out_channels, int* out_h, int* out_w) {

@@ -416,21 +416,17 @@ extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* inpu
                                                    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
                                                    vfi_stream_t stream);
 
-// development knob: 0 forces the general kernel (tests compare the two)
-static int g_defor_fast = 1;
-extern "C" void vfi_debug_defor(int fast) { g_defor_fast = fast; }
-
-extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, const float* input2,
-                                               const float* input3, const float* input4, float* output,
-                                               int batch, int channel, int h, int w, int filter_size,
-                                               vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
-                                               vfi_stream_t stream) {
+static int defor_forward(bool allow_staged, int variant, const float* input1, const float* input2,
+                         const float* input3, const float* input4, float* output,
+                         int batch, int channel, int h, int w, int filter_size,
+                         vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                         vfi_stream_t stream) {
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_size <= 0) return VFI_ERR_SHAPE;
     if (!input1 || !input2 || !input3 || !output) return VFI_ERR_SHAPE;
     if (variant != VFI_DEFOR_NOFILTER && !input4) return VFI_ERR_SHAPE;
     const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (filter_size == 4 && g_defor_fast && variant >= 0 && variant <= 2) {
+    if (filter_size == 4 && allow_staged && variant >= 0 && variant <= 2) {
         // LDS-staged kernel (filterinterp_defor_lds.hip); -1 = not applicable
         const int err = vfi_filterinterp_forward_defor_lds(variant, input1, input2, input3, input4, output, batch,
                                                            channel, h, w, s1, s2, s3, s4, stream);
@@ -456,6 +452,25 @@ extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, 
         return VFI_ERR_SHAPE;
     }
     return launch_status();
+}
+
+extern "C" int vfi_filterinterp_forward_defor(int variant, const float* input1, const float* input2,
+                                               const float* input3, const float* input4, float* output,
+                                               int batch, int channel, int h, int w, int filter_size,
+                                               vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                               vfi_stream_t stream) {
+    return defor_forward(true, variant, input1, input2, input3, input4, output, batch, channel, h, w, filter_size, s1, s2, s3,
+                         s4, stream);
+}
+
+// internal (not in vfi_hip.h): always the general one-thread-per-pixel kernel -- the tests compare the staged kernel with it
+extern "C" int vfi_filterinterp_forward_defor_general(int variant, const float* input1, const float* input2,
+                                                       const float* input3, const float* input4, float* output,
+                                                       int batch, int channel, int h, int w, int filter_size,
+                                                       vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
+                                                       vfi_stream_t stream) {
+    return defor_forward(false, variant, input1, input2, input3, input4, output, batch, channel, h, w, filter_size, s1, s2, s3,
+                         s4, stream);
 }
 
 extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1, const float* input2,

@@ -26,7 +26,7 @@ namespace vfi {
 
 #define DF_TW 64
 #define DF_TH 4
-#define DF_THREADS (DF_TW * DF_TH)                  // 512: one pixel per thread
+#define DF_THREADS (DF_TW * DF_TH)                  // 256: one pixel per thread
 #define DF_HDR 16
 #define DF_RING_FLOATS 13040
 #define DF_RMAX 5
@@ -313,19 +313,6 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
 
 using namespace vfi;
 
-static int df_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
-
 // returns -1 when this path does not apply (the caller uses the direct kernels)
 extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* input1, const float* input2,
                                                    const float* input3, const float* input4, float* output,
@@ -345,7 +332,7 @@ extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* inpu
     const int ntiles = (int)nt;
     // channel groups over blockIdx.y when that shortens the tail: two workgroups per CU at a time; every extra
     // group re-reads flow, offsets and filter (up to 200 B/pixel) next to 8 B/pixel/channel of image traffic
-    const int slots = df_cu_count() * 2;
+    const int slots = device_cu_count() * 2;
     const double fixed = (variant == VFI_DEFOR_NOFILTER) ? 136.0 : 200.0;
     int best_groups = 1;
     double best_cost = 0.0;

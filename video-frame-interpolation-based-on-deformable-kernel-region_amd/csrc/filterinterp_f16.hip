@@ -316,19 +316,6 @@ __global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
 #undef F16_RUN
 }
 
-static int f16_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
-
 }  // namespace vfi
 
 using namespace vfi;
@@ -362,7 +349,7 @@ extern "C" int vfi_filterinterp_forward_ori_f16(const void* input1, const float*
                                                        filter_channels, s1, s2, s3, stream);
     const int ntiles = (int)nt;
     // split the channel range over blockIdx.y when that shortens the tail (as the fp32 kernel)
-    const int slots = f16_cu_count() * 2;
+    const int slots = device_cu_count() * 2;
     int best_groups = 1;
     double best_cost = 0.0;
     for (int g = 1; g <= 8 && g <= channel; g *= 2) {

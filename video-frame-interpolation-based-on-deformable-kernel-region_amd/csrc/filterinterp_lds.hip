@@ -178,14 +178,38 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
     // ---- block -> tile (XCD-contiguous bands)
     const int bid = blockIdx.x;
-    // Measured (1080p, C=196): the plain order, consecutive tiles dealt round-robin over the XCDs,
-    // is ~12 % faster than giving every XCD a contiguous band of tiles, so that is the default;
-    // flag bit 1 selects the band mapping for experiments.
-    const int tile = (flags & 2) ? (bid % FI_XCDS) * per_xcd + bid / FI_XCDS : bid;
-    if (tile >= ntiles) return;                             // whole workgroup leaves together
-    const int b = tile / (tiles_x * tiles_y);
-    const int trem = tile - b * (tiles_x * tiles_y);
-    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and a tile's window rows share
+    // their first and last 128-byte line with the horizontal neighbours' windows.  Default: G = 4 horizontally
+    // consecutive tiles go to ONE XCD (workgroups b, b + 8, b + 16, b + 24 share an XCD and start together), so
+    // three of four shared lines are L2 hits: EA read requests per C=196 launch 39.1 M -> 31.2 M (5.0 -> 4.0 GB),
+    // 1-9 % less time depending on the box.  Larger departures from raster order lose more than they save:
+    // XCD-contiguous bands +12 % time, 4x2 / 2x2 tile blocks per XCD -25 % reads but +15-30 % time
+    // (tools/fi_xcd_exp.sh).  The other mappings remain selectable in a development build.
+    int tile = (flags & 2) ? (bid % FI_XCDS) * per_xcd + bid / FI_XCDS : bid;
+    if ((flags >> 2) & 3) {
+        const int G = 1 << ((flags >> 2) & 3);
+        const int xs = bid % FI_XCDS, k = bid / FI_XCDS;
+        tile = ((k / G) * FI_XCDS + xs) * G + (k % G);
+    }
+    int b, tyi, txi;
+    if (flags & 48) {
+        // experiment: GW x GH tiles per XCD (flags bit 4: 4 x 2, bit 5: 2 x 2)
+        const int GW = (flags & 16) ? 4 : 2, GH = 2, GN = GW * GH;
+        const int xs = bid % FI_XCDS, k = bid / FI_XCDS;
+        const int j = (k / GN) * FI_XCDS + xs, m = k % GN;
+        const int gpr = (tiles_x + GW - 1) / GW, gpc = (tiles_y + GH - 1) / GH;
+        b = j / (gpr * gpc);
+        const int jr = j - b * (gpr * gpc);
+        const int gy = jr / gpr, gx = jr - gy * gpr;
+        txi = gx * GW + m % GW;
+        tyi = gy * GH + m / GW;
+        if (txi >= tiles_x || tyi >= tiles_y || b * tiles_x * tiles_y >= ntiles) return;
+    } else {
+        if (tile >= ntiles) return;                         // whole workgroup leaves together
+        b = tile / (tiles_x * tiles_y);
+        const int trem = tile - b * (tiles_x * tiles_y);
+        tyi = trem / tiles_x; txi = trem - tyi * tiles_x;
+    }
     const int c_begin = blockIdx.y * ch_per_group;
     const int c_end = min(channel, c_begin + ch_per_group);
 
@@ -294,22 +318,15 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
 using namespace vfi;
 
-// development knobs (tools/bench_ops.py --knob): 0 = defaults
-static int g_fi_flags = 0, g_fi_groups = 0;
-extern "C" void vfi_debug_filterinterp(int flags, int groups) { g_fi_flags = flags; g_fi_groups = groups; }
-
-static int fi_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
+// Kernel flags: bit 0 issue the next DMA before / after the compute phase; bit 1 XCD-contiguous bands of tiles;
+// bits 2-3 log2 of the tiles per XCD group (default 2: four horizontally consecutive tiles on one XCD, see the
+// kernel); bits 4-5 two-dimensional groups; bits 8.. ring depth.  g_fi_groups: channel groups, 0 = chosen below.
+#define FI_DEFAULT_FLAGS 8
+VFI_KNOB(int, g_fi_flags, FI_DEFAULT_FLAGS);
+VFI_KNOB(int, g_fi_groups, 0);
+#ifdef VFI_DEV
+extern "C" void vfi_dev_filterinterp(int flags, int groups) { g_fi_flags = flags; g_fi_groups = groups; }
+#endif
 
 // returns -1 when this path does not apply (caller uses the direct kernel)
 extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float* input2, const float* input3,
@@ -322,12 +339,12 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
     const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
     if (nt > (1 << 28)) return -1;
     const int ntiles = (int)nt;
-    const int per_xcd = (ntiles + FI_XCDS - 1) / FI_XCDS;
+    const int per_xcd = (((ntiles + FI_XCDS - 1) / FI_XCDS) + 7) & ~7;         // (a multiple of 8: the tile-group experiments)
 
     // split the channel range over blockIdx.y when that shortens the tail: two workgroups per
     // CU run at a time; every extra group re-reads the flow + 16 filter planes (72 B/pixel)
     // next to 8 B/pixel/channel of image traffic
-    const int slots = fi_cu_count() * 2;
+    const int slots = device_cu_count() * 2;
     int best_groups = 1;
     double best_cost = 0.0;
     for (int g = 1; g <= 8 && g <= channel; g *= 2) {
@@ -341,7 +358,13 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
 
-    const dim3 grid((unsigned)(per_xcd * FI_XCDS), (unsigned)groups, 1);
+    int grid_x = per_xcd * FI_XCDS;
+    if (g_fi_flags & 48) {
+        const int GW = (g_fi_flags & 16) ? 4 : 2, GH = 2;
+        const int ngroups = ((tiles_x + GW - 1) / GW) * ((tiles_y + GH - 1) / GH) * batch;
+        grid_x = ((ngroups + FI_XCDS - 1) / FI_XCDS) * FI_XCDS * GW * GH;
+    }
+    const dim3 grid((unsigned)grid_x, (unsigned)groups, 1);
     hipLaunchKernelGGL(fi_forward_ori_lds, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
                        input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags);
     return launch_status();

@@ -219,19 +219,6 @@ __global__ __launch_bounds__(FN_THREADS, 4) void fi_forward_ori_lds_n(
 
 using namespace vfi;
 
-static int fn_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
-
 // returns -1 when this path does not apply (the caller uses the direct kernel)
 extern "C" int vfi_filterinterp_forward_ori_lds_n(const float* input1, const float* input2, const float* input3,
                                                    float* output, int batch, int channel, int h, int w, int fs,
@@ -245,7 +232,7 @@ extern "C" int vfi_filterinterp_forward_ori_lds_n(const float* input1, const flo
     const int ntiles = (int)nt;
     // channel groups over blockIdx.y when that shortens the tail (two workgroups per CU at a time); every extra
     // group re-reads flow + filter next to 8 B/pixel/channel of image traffic
-    const int slots = fn_cu_count() * 2;
+    const int slots = device_cu_count() * 2;
     const double fixed = 4.0 * (2 + fs * fs);
     int best_groups = 1;
     double best_cost = 0.0;

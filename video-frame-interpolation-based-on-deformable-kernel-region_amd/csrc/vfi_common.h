@@ -63,6 +63,18 @@ inline dim3 pixel_grid(int w, int h, int batch) {
     return dim3((unsigned)((w + VFI_TX - 1) / VFI_TX), (unsigned)((h + VFI_TY - 1) / VFI_TY), (unsigned)batch);
 }
 
+// Development knobs: tunables that experiments (tools/) flip at run time exist only in a -DVFI_DEV build of the
+// library (make OUT=../lib_dev EXTRA=-DVFI_DEV); in the product they are compile-time constants and no setter is
+// exported, so no caller or thread can change kernel selection for another.
+#ifdef VFI_DEV
+#define VFI_KNOB(type, name, value) static type name = value
+#else
+#define VFI_KNOB(type, name, value) static constexpr type name = value
+#endif
+
+// compute units of the CURRENT device (cached per device id)
+int device_cu_count();
+
 inline int launch_status() {
     return hipGetLastError() == hipSuccess ? VFI_OK : VFI_ERR_LAUNCH;
 }

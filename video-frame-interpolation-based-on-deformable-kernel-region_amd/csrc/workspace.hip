@@ -46,6 +46,17 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
     return p;
 }
 
+int device_cu_count() {
+    static int cus[64];                             // 0 = not asked yet; racing first calls write the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cus[dev];
+}
+
 }  // namespace vfi
 
 using namespace vfi;

@@ -4,7 +4,7 @@ from torch.autograd import Function
 
 import depthflowprojection_cuda as my_lib
 
-from .._common import require_gpu
+from .._common import check, require_gpu
 
 
 class DepthFlowProjectionLayer(Function):
@@ -19,8 +19,7 @@ class DepthFlowProjectionLayer(Function):
                             device=input1.device)
         output = torch.empty_like(input1)
         err = my_lib.DepthFlowProjectionLayer_gpu_forward(input1, input2, count, output, fillhole)
-        if err != 0:
-            print(err)
+        check(err, "DepthFlowProjectionLayer_gpu_forward")
         ctx.save_for_backward(input1, input2, count, output)
         ctx.fillhole = fillhole
         return output

@@ -8,7 +8,7 @@ from torch.autograd import Function
 
 import filterinterpolation_cuda as my_lib
 
-from .._common import require_gpu
+from .._common import check, require_gpu
 
 
 class FilterInterpolationLayer(Function):
@@ -21,8 +21,7 @@ class FilterInterpolationLayer(Function):
         # the kernel writes every element: no zero fill needed (reference: .zero_(), :34)
         output = torch.empty_like(input1)
         err = my_lib.FilterInterpolationLayer_gpu_forward_ori(input1, input2, input3, output)
-        if err != 0:
-            print(err)
+        check(err, "FilterInterpolationLayer_gpu_forward_ori")
         ctx.save_for_backward(input1, input2, input3)
         return output
 
