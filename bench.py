@@ -360,7 +360,9 @@ def cpu_baseline(torch, cabi, wl, dev, args):
     csel = 16
     frame, filt = wl.frames[0].cpu().numpy(), wl.filters[0].cpu().numpy()
     depth, flow = wl.depth[0].cpu().numpy(), wl.flows[0][1].cpu().numpy()
-    ctx_sel = np.ascontiguousarray(wl.ctx[0][:, :csel].cpu().numpy())
+    ctx_dev = torch.empty((1, csel, wl.h, wl.w), dtype=torch.float32, device=dev)      # fresh dense strides: a channel slice of a
+    ctx_dev.copy_(wl.ctx[0][:, :csel])                                                 # B = 1 tensor keeps the 196-channel batch stride
+    ctx_sel = ctx_dev.cpu().numpy()
     corr_np = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in wl.corr[0]]
     proj, _ = oracle.depthflowproj_fwd(flow, depth, 1)
 
@@ -399,7 +401,7 @@ def cpu_baseline(torch, cabi, wl, dev, args):
     # parity of the GPU path on the same sample (GPU fed the oracle's projected flow -> exact compare)
     gproj = torch.tensor(proj, device=dev)
     out = torch.empty((1, csel, wl.h, wl.w), dtype=torch.float32, device=dev)
-    assert cabi.filterinterp_forward_ori(torch.tensor(ctx_sel, device=dev), gproj, wl.filters[0], out, direct=args.direct) == 0
+    assert cabi.filterinterp_forward_ori(ctx_dev, gproj, wl.filters[0], out, direct=args.direct) == 0
     out3 = torch.empty_like(wl.frames[0])
     assert cabi.filterinterp_forward_ori(wl.frames[0], gproj, wl.filters[0], out3, direct=args.direct) == 0
     cnt = torch.empty_like(wl.count)

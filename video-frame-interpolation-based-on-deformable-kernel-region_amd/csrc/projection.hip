@@ -55,6 +55,8 @@
 
 #include <limits.h>
 
+#include <type_traits>
+
 namespace vfi {
 
 #define PROJ_TW 64                  // output tile
@@ -63,6 +65,7 @@ namespace vfi {
 #define PROJ_BLK 16                 // source block edge
 #define PROJ_ADD_BITS 25            // |scaled addend| < 2^25
 #define PROJ_ADD_CELL 32            // addends per cell that fit beside it in 32 bits
+#define PROJ_CLS_BITS 12            // binary orders of magnitude of weight per accumulation pass (DepthFlowProjection)
 #define PROJ_BLOCK_CAP 64           // output tiles one block may reach before the call takes the fallback
 
 // workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
@@ -77,6 +80,7 @@ namespace vfi {
 #define PROJ_WS_FLAG 0
 #define PROJ_WS_DIRTY 2
 #define PROJ_TILE_WORDS 8
+#define PROJ_INV_BITS 0x7f7fffff       // a weight's bits are stored as this minus them where the SMALLEST is wanted
 
 // rmw / cmw: 32-bit words per image row / column of the two bitmaps; rowmap / colmap: their word offsets
 // inside the bit buffer; off_tile / off_list: word offsets of the tile records and of the hole list
@@ -210,7 +214,7 @@ __device__ __forceinline__ int row16_max(int v) {
 // instruction (lane k = field k) -- the atomics are the expensive part of this kernel (one wave instruction
 // per ~50 ns per CU at the memory side, whatever its lane count).
 __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict__ ws, int b, int lane, int x, int y0,
-                                             int dlmin, int dlmax, int dtmin, int dtmax, int vbits, int cbits) {
+                                             int dlmin, int dlmax, int dtmin, int dtmax, int vbits, int cbits, int mbits) {
     const bool any = dlmin != INT_MAX;
     const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
     // top-left targets of the block lie in [X0, X1] x [Y0, Y1]; a target (L, T) feeds columns L, L + 1, rows T, T + 1
@@ -237,7 +241,7 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
             const int sy0 = max(y0, oy0 - 1 - dtmax), sy1 = min(by1, ty1 - dtmin);
             const bool hit = any && sx0 <= sx1 && sy0 <= sy1;
             // fields as stored (0 = nothing), merged over the four blocks
-            int f0m = 0, f1m = 0, f2m = 0, f3m = 0, f4m = 0, f5m = 0;
+            int f0m = 0, f1m = 0, f2m = 0, f3m = 0, f4m = 0, f5m = 0, f6m = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int sl = 16 * q + 15;
@@ -245,11 +249,12 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
                 f0m = max(f0m, 32767 - __builtin_amdgcn_readlane(sx0, sl)); f1m = max(f1m, 32767 - __builtin_amdgcn_readlane(sy0, sl));
                 f2m = max(f2m, __builtin_amdgcn_readlane(sx1, sl) + 1); f3m = max(f3m, __builtin_amdgcn_readlane(sy1, sl) + 1);
                 f4m = max(f4m, __builtin_amdgcn_readlane(vbits, sl)); f5m = max(f5m, __builtin_amdgcn_readlane(cbits, sl));
+                f6m = max(f6m, __builtin_amdgcn_readlane(mbits, sl));
             }
             if (f2m == 0) continue;
             int* e = ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS;
-            const int v = lane == 0 ? f0m : lane == 1 ? f1m : lane == 2 ? f2m : lane == 3 ? f3m : lane == 4 ? f4m : f5m;
-            if (lane < 6) atomicMax(&e[lane], v);
+            const int v = lane == 0 ? f0m : lane == 1 ? f1m : lane == 2 ? f2m : lane == 3 ? f3m : lane == 4 ? f4m : lane == 5 ? f5m : f6m;
+            if (lane < 7) atomicMax(&e[lane], v);
         }
 }
 
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
     const int xc = min(x, g.w - 1);
     const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
-    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
     constexpr int GROUP = UP ? 4 : PROJ_TH;                 // rows whose loads are issued together
 #pragma unroll 1
     for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
@@ -293,17 +298,20 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
             const int dl = L - x, dt = T - y;
             dlmin = min(dlmin, valid ? dl : INT_MAX); dlmax = max(dlmax, valid ? dl : INT_MIN);
             dtmin = min(dtmin, valid ? dt : INT_MAX); dtmax = max(dtmax, valid ? dt : INT_MIN);
-            // the addends' magnitudes; non-negative floats order like their bit patterns
-            const float av = DEPTH ? fmaxf(fabsf(raw[k].d * fx), fabsf(raw[k].d * fy)) : fmaxf(fabsf(fx), fabsf(fy));
-            vbits = max(vbits, valid ? __float_as_int(av) : 0);
-            if constexpr (DEPTH) cbits = max(cbits, valid ? __float_as_int(fabsf(raw[k].d)) : 0);
-            else cbits = max(cbits, valid ? __float_as_int(1.0f) : 0);
+            // the largest |flow| and, with depth, the largest and the smallest |weight| (the latter stored inverted, so
+            // that "largest" merges it); non-negative floats order like their bit patterns
+            vbits = max(vbits, valid ? __float_as_int(fmaxf(fabsf(fx), fabsf(fy))) : 0);
+            if constexpr (DEPTH) {
+                const int db = __float_as_int(fabsf(raw[k].d));
+                cbits = max(cbits, valid ? db : 0);
+                mbits = max(mbits, valid && db != 0 ? PROJ_INV_BITS - db : 0);
+            }
         }
     }
     dlmin = row16_min(dlmin); dlmax = row16_max(dlmax);
     dtmin = row16_min(dtmin); dtmax = row16_max(dtmax);
-    vbits = row16_max(vbits); cbits = row16_max(cbits);
-    scan_scatter(g, ws, b, lane, x, y0, dlmin, dlmax, dtmin, dtmax, vbits, cbits);
+    vbits = row16_max(vbits); cbits = row16_max(cbits); mbits = row16_max(mbits);
+    scan_scatter(g, ws, b, lane, x, y0, dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits);
 }
 
 // K0 for a full-resolution flow: the same, with 16-byte lanes (a walk with 4-byte lanes reaches ~4 TB/s on this
@@ -328,9 +336,9 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
     }
-    __shared__ int sblk[16][6];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits
+    __shared__ int sblk[16][7];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 96) sblk[tid / 6][tid % 6] = (tid % 6 == 0 || tid % 6 == 2) ? INT_MAX : (tid % 6 == 1 || tid % 6 == 3) ? INT_MIN : 0;
+    if (tid < 112) sblk[tid / 7][tid % 7] = (tid % 7 == 0 || tid % 7 == 2) ? INT_MAX : (tid % 7 == 1 || tid % 7 == 3) ? INT_MIN : 0;
     const int per_img = groups_x * g.tiles_y;
     const int b = blockIdx.x / per_img;
     const int rem = blockIdx.x - b * per_img;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         if constexpr (DEPTH) qd[r] = buf_f32x4(pl.d, x0 * 4, min(yw + r, g.h - 1) * src.dh * 4);
     }
     __syncthreads();
-    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0;
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -359,26 +367,30 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
             if (valid) {
                 dlmin = min(dlmin, L - x); dlmax = max(dlmax, L - x);
                 dtmin = min(dtmin, T - y); dtmax = max(dtmax, T - y);
-                // the addends' magnitudes; non-negative floats order like their bit patterns
-                const float av = DEPTH ? fmaxf(fabsf(qd[r][j] * fx), fabsf(qd[r][j] * fy)) : fmaxf(fabsf(fx), fabsf(fy));
-                vbits = max(vbits, __float_as_int(av));
-                cbits = max(cbits, DEPTH ? __float_as_int(fabsf(qd[r][j])) : __float_as_int(1.0f));
+                // the largest |flow|, the largest and (inverted) the smallest |weight|; non-negative floats order like
+                // their bit patterns
+                vbits = max(vbits, __float_as_int(fmaxf(fabsf(fx), fabsf(fy))));
+                if constexpr (DEPTH) {
+                    const int db = __float_as_int(fabsf(qd[r][j]));
+                    cbits = max(cbits, db);
+                    if (db != 0) mbits = max(mbits, PROJ_INV_BITS - db);
+                }
             }
         }
     // a block is four lanes wide
     dlmin = quad_min(dlmin); dlmax = quad_max(dlmax); dtmin = quad_min(dtmin); dtmax = quad_max(dtmax);
-    vbits = quad_max(vbits); cbits = quad_max(cbits);
+    vbits = quad_max(vbits); cbits = quad_max(cbits); mbits = quad_max(mbits);
     if ((lane & 3) == 0 && dlmin != INT_MAX) {
         int* e = sblk[lane >> 2];
         atomicMin(&e[0], dlmin); atomicMax(&e[1], dlmax); atomicMin(&e[2], dtmin); atomicMax(&e[3], dtmax);
-        atomicMax(&e[4], vbits); atomicMax(&e[5], cbits);
+        atomicMax(&e[4], vbits); atomicMax(&e[5], cbits); atomicMax(&e[6], mbits);
     }
     __syncthreads();
     // wave w: the four blocks of tile column w, spoken for by lanes 15, 31, 47, 63 as in proj_scan
     const int* e = sblk[4 * wave + (lane >> 4)];
     const int xb = (gxi * 4 + wave) * PROJ_TW + (lane >> 4) * PROJ_BLK + 15;      // the block's last column
     const bool speaker = (lane & 15) == 15 && xb - 15 < g.w;
-    scan_scatter(g, ws, b, lane, xb, y0, speaker ? e[0] : INT_MAX, e[1], e[2], e[3], e[4], e[5]);
+    scan_scatter(g, ws, b, lane, xb, y0, speaker ? e[0] : INT_MAX, e[1], e[2], e[3], e[4], e[5], e[6]);
 }
 
 // the two halves of a packed sum, exactly: S = hi * 2^32 + lo with both in int32
@@ -428,12 +440,18 @@ template <bool DEPTH> struct ProjLds {
 };
 
 // one source pixel into the grid
+// cls / ncls / emax: with depth, only the sources of weight class cls are taken (see proj_pull)
 template <bool DEPTH>
 __device__ __forceinline__ void pull_add(unsigned long long* accv, typename ProjCountCell<DEPTH>::type* accc,
                                          float fx, float fy, float d, int px, int py, bool on, unsigned wbits, unsigned hbits,
-                                         int cx, int cy, float sv, float scn) {
+                                         int cx, int cy, float sv, float scn, int cls, int ncls, int emax) {
     int L, T;
-    const bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
+    bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
+    if constexpr (DEPTH) {
+        const int delta = emax - ((__float_as_int(d) >> 23) & 0xff);
+        const int mine = min((delta >= PROJ_CLS_BITS ? 1 : 0) + (delta >= 2 * PROJ_CLS_BITS ? 1 : 0) + (delta >= 3 * PROJ_CLS_BITS ? 1 : 0), ncls - 1);
+        valid = valid && mine == cls;
+    }
     const unsigned c = (unsigned)(L - cx), r = (unsigned)(T - cy);
 #if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 3
     if (valid && on && c < PROJ_AW && r < PROJ_AH && sv == 12345.0f) {
@@ -474,13 +492,13 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
 #endif
     if (tile == 0 && tid == 0) ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;
     int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
-    const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5];
+    const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5], e6 = entry[6];
     const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
 
     if (fallback) {
         __syncthreads();
-        if (tid < 6) entry[tid] = 0;
+        if (tid < 7) entry[tid] = 0;
         // the reference's own scheme: this tile as SOURCE tile, global atomics into the dense scratch
         // planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
         const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
@@ -508,25 +526,67 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
 
     for (int i = tid; i < ProjLds<DEPTH>::total / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    if (tid < 6) entry[tid] = 0;                            // every thread has read the record: empty for the next call
+    if (tid < 7) entry[tid] = 0;                            // every thread has read the record: empty for the next call
 #ifdef PROJ_STAMPS
     const unsigned long long st_ta = __builtin_amdgcn_s_memtime() + (e0 & 0);      // (after the record has arrived)
 #endif
 
     const int ux0 = 32767 - e0, uy0 = 32767 - e1;
     const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
-    // fixed-point scales: every addend that reaches this tile is below 2^e with e from the blocks' maxima, so
-    // addend * 2^(25 - e) is below 2^25 in magnitude
-    int ev = 0, ec = 0;
-    (void)frexpf(__int_as_float(e4), &ev);
-    (void)frexpf(__int_as_float(e5), &ec);
-    // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
-    int kv = max(-100, min(100, PROJ_ADD_BITS - ev)), kc = max(-100, min(100, PROJ_ADD_BITS - ec));
+    // Fixed-point scales: a value addend is below 2^(ef + ec) and a weight below 2^ec, with 2^ef / 2^ec above the
+    // largest |flow| / |weight| that can reach this tile (from K0), so addend * 2^(25 - e) is below 2^25.
+    // DepthFlowProjection: the weights (inverse depth, 1e-6 + exp(-d): DAIN_slowmotion.py:143) can span many
+    // orders of magnitude inside one tile, e.g. at the edge of a near object in front of sky, and a cell that only
+    // far-away sources reach must still get full relative precision (the reference's fp32 sums give it that).  So
+    // the sources are taken in up to four passes by weight class -- class j: weights within 2^(-12 j) .. 2^(-12 j - 12)
+    // of the largest, the last class everything below -- each pass with its own scale, exact integer sums, one
+    // rounding to float, and the classes' results are added.  Almost every tile has one class.
+    int ef = 0, ec = 0;
+    (void)frexpf(__int_as_float(e4), &ef);
+    if constexpr (DEPTH) (void)frexpf(__int_as_float(e5), &ec);
+    const int emax = (e5 >> 23) & 0xff, emin = e6 ? ((PROJ_INV_BITS - e6) >> 23) & 0xff : emax;
+    const int ncls = DEPTH ? min(4, max(0, emax - emin) / PROJ_CLS_BITS + 1) : 1;
 
     // epilogue geometry: a lane owns four consecutive cells of a row, 16 lanes a row, a wave four rows
     const int q = lane & 15, rw = lane >> 4;
     const int xq = ox0 + 4 * q;
     float resx[PROJ_EPI_ITERS][4], resy[PROJ_EPI_ITERS][4], resc[PROJ_EPI_ITERS][4];    // the tile's sums, not yet normalised
+    // the count cells a lane's four tile cells are made of, summed (the number of addends sits in the high half with depth)
+    auto count_sums = [&](int it, ccell (&c4)[4]) {
+        const int yl = it * 4 * PROJ_NW + wave * 4 + rw;
+        ccell n[2][5];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if constexpr (DEPTH) {
+                const uint4* pc = reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_VS + 4 * q);
+                const uint4 c01 = pc[0], c23 = pc[1];
+                n[r][0] = c01.x | ((unsigned long long)c01.y << 32); n[r][1] = c01.z | ((unsigned long long)c01.w << 32);
+                n[r][2] = c23.x | ((unsigned long long)c23.y << 32); n[r][3] = c23.z | ((unsigned long long)c23.w << 32);
+                n[r][4] = accc[(yl + r) * PROJ_VS + 4 * q + 4];
+            } else {
+                const uint4 c03 = *reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_CS4 + 4 * q);
+                n[r][0] = c03.x; n[r][1] = c03.y; n[r][2] = c03.z; n[r][3] = c03.w;
+                n[r][4] = accc[(yl + r) * PROJ_CS4 + 4 * q + 4];
+            }
+        }
+        const bool ylast = oy0 + yl == g.h - 1;                            // B == T there: the row adds twice
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool xlast = xq + j == g.w - 1;                          // R == L there: the column adds twice
+            ccell c0 = n[0][j] + n[0][j + 1], c1 = n[1][j] + n[1][j + 1];
+            if (xlast) { c0 += n[0][j + 1]; c1 += n[1][j + 1]; }
+            ccell c = c0 + c1;
+            if (ylast) c += c1;
+            c4[j] = c;
+        }
+    };
+    // one weight class: accumulate, check, sum.  FIRST: the results are assigned, not added -- the one-class case, almost
+    // every tile, then holds no partial results in registers across the accumulation loop (two instantiations)
+    auto run_class = [&](auto first_tag, int cls) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
+    int kc = max(-100, min(100, PROJ_ADD_BITS - (ec - PROJ_CLS_BITS * cls)));
+    int kv = max(-100, min(100, PROJ_ADD_BITS - (ef + ec - PROJ_CLS_BITS * cls)));
     for (int attempt = 0;; ++attempt) {
         const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
         // The rectangle is walked in strips of up to 64 lanes.  A full strip: the workgroup's waves take its rows
@@ -555,7 +615,8 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
                         const int py = uy0 + rowk;
                         float fx, fy;
                         pix_flow<UP>(src, raw[k], px, py, fx, fy);
-                        pull_add<DEPTH>(accv, accc, fx, fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn);
+                        pull_add<DEPTH>(accv, accc, fx, fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn,
+                                        cls, ncls, emax);
                     }
                 }
             }
@@ -592,7 +653,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
 #pragma unroll
                         for (int j = 0; j < 4; ++j)                         // (a quad may reach past the row: x < w)
                             pull_add<DEPTH>(accv, accc, qx[k][j], qy[k][j], qd[k][j], px + j, uy0 + rowk, on && px + j < g.w, wbits, hbits,
-                                            ox0 - 1, oy0 - 1, sv, scn);
+                                            ox0 - 1, oy0 - 1, sv, scn, cls, ncls, emax);
                     }
                 }
             }
@@ -601,53 +662,19 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         if (!attempt) st_t1 = __builtin_amdgcn_s_memtime();
 #endif
         __syncthreads();
-        // a cell = the grid cells of the top-left targets (x, y), (x - 1, y), (x, y - 1), (x - 1, y - 1): a lane
-        // reads the five grid cells above and the five beside its four cells
+        if (attempt) break;
+        // did every cell stay within the addends its 32-bit halves can hold?
         int nmax = 0;
 #pragma unroll
         for (int it = 0; it < PROJ_EPI_ITERS; ++it) {
-            const int yl = it * 4 * PROJ_NW + wave * 4 + rw;
-            unsigned long long a[2][5];
-            ccell n[2][5];
+            ccell c4[4];
+            count_sums(it, c4);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint4* pv = reinterpret_cast<const uint4*>(accv + (yl + r) * PROJ_VS + 4 * q);
-                const uint4 v01 = pv[0], v23 = pv[1];
-                a[r][0] = v01.x | ((unsigned long long)v01.y << 32); a[r][1] = v01.z | ((unsigned long long)v01.w << 32);
-                a[r][2] = v23.x | ((unsigned long long)v23.y << 32); a[r][3] = v23.z | ((unsigned long long)v23.w << 32);
-                a[r][4] = accv[(yl + r) * PROJ_VS + 4 * q + 4];
-                if constexpr (DEPTH) {
-                    const uint4* pc = reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_VS + 4 * q);
-                    const uint4 c01 = pc[0], c23 = pc[1];
-                    n[r][0] = c01.x | ((unsigned long long)c01.y << 32); n[r][1] = c01.z | ((unsigned long long)c01.w << 32);
-                    n[r][2] = c23.x | ((unsigned long long)c23.y << 32); n[r][3] = c23.z | ((unsigned long long)c23.w << 32);
-                    n[r][4] = accc[(yl + r) * PROJ_VS + 4 * q + 4];
-                } else {
-                    const uint4 c03 = *reinterpret_cast<const uint4*>(accc + (yl + r) * PROJ_CS4 + 4 * q);
-                    n[r][0] = c03.x; n[r][1] = c03.y; n[r][2] = c03.z; n[r][3] = c03.w;
-                    n[r][4] = accc[(yl + r) * PROJ_CS4 + 4 * q + 4];
+            for (int j = 0; j < 4; ++j)
+                if (xq + j < g.w && oy0 + it * 4 * PROJ_NW + wave * 4 + rw < g.h) {
+                    if constexpr (DEPTH) nmax = max(nmax, packed_hi(c4[j])); else nmax = max(nmax, (int)min(c4[j], (ccell)0x7fffffffu));
                 }
-            }
-            const bool ylast = oy0 + yl == g.h - 1;                        // B == T there: the row adds twice
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool xlast = xq + j == g.w - 1;                      // R == L there: the column adds twice
-                unsigned long long h0 = a[0][j] + a[0][j + 1], h1 = a[1][j] + a[1][j + 1];
-                ccell c0 = n[0][j] + n[0][j + 1], c1 = n[1][j] + n[1][j + 1];
-                if (xlast) { h0 += a[0][j + 1]; h1 += a[1][j + 1]; c0 += n[0][j + 1]; c1 += n[1][j + 1]; }
-                unsigned long long v = h0 + h1;
-                ccell c = c0 + c1;
-                if (ylast) { v += h1; c += c1; }
-                // exact integer sums -> float once
-                resx[it][j] = ldexpf((float)packed_hi(v), -kv); resy[it][j] = ldexpf((float)packed_lo(v), -kv);
-                if constexpr (DEPTH) resc[it][j] = ldexpf((float)packed_lo(c), -kc); else resc[it][j] = (float)c;
-                if (xq + j < g.w && oy0 + yl < g.h) {
-                    if constexpr (DEPTH) nmax = max(nmax, packed_hi(c)); else nmax = max(nmax, (int)min(c, (ccell)0x7fffffffu));
-                }
-            }
         }
-        if (attempt) break;
-        // did every cell stay within the addends its 32-bit halves can hold?
         nmax = wave_max_i32(nmax);
         if (lane == 0 && nmax > PROJ_ADD_CELL) atomicMax(&s_misc[0], nmax);
         __syncthreads();
@@ -658,6 +685,46 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         kv -= shift; kc -= shift;
         for (int i = tid; i < ProjLds<DEPTH>::acc_bytes / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+    }
+    // a cell = the grid cells of the top-left targets (x, y), (x - 1, y), (x, y - 1), (x - 1, y - 1): a lane reads the
+    // five grid cells above and the five beside its four cells; exact integer sums -> float once (per class)
+#pragma unroll
+    for (int it = 0; it < PROJ_EPI_ITERS; ++it) {
+        const int yl = it * 4 * PROJ_NW + wave * 4 + rw;
+        unsigned long long a[2][5];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint4* pv = reinterpret_cast<const uint4*>(accv + (yl + r) * PROJ_VS + 4 * q);
+            const uint4 v01 = pv[0], v23 = pv[1];
+            a[r][0] = v01.x | ((unsigned long long)v01.y << 32); a[r][1] = v01.z | ((unsigned long long)v01.w << 32);
+            a[r][2] = v23.x | ((unsigned long long)v23.y << 32); a[r][3] = v23.z | ((unsigned long long)v23.w << 32);
+            a[r][4] = accv[(yl + r) * PROJ_VS + 4 * q + 4];
+        }
+        ccell c4[4];
+        count_sums(it, c4);
+        const bool ylast = oy0 + yl == g.h - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool xlast = xq + j == g.w - 1;
+            unsigned long long h0 = a[0][j] + a[0][j + 1], h1 = a[1][j] + a[1][j + 1];
+            if (xlast) { h0 += a[0][j + 1]; h1 += a[1][j + 1]; }
+            unsigned long long v = h0 + h1;
+            if (ylast) v += h1;
+            const float px_ = ldexpf((float)packed_hi(v), -kv), py_ = ldexpf((float)packed_lo(v), -kv);
+            float pc_;
+            if constexpr (DEPTH) pc_ = ldexpf((float)packed_lo(c4[j]), -kc); else pc_ = (float)c4[j];
+            if constexpr (FIRST) { resx[it][j] = px_; resy[it][j] = py_; resc[it][j] = pc_; }
+            else { resx[it][j] += px_; resy[it][j] += py_; resc[it][j] += pc_; }
+        }
+    }
+    };
+    run_class(std::true_type{}, 0);
+    for (int cls = 1; cls < ncls; ++cls) {
+        __syncthreads();                                        // every lane has read the previous class's sums
+        for (int i = tid; i < ProjLds<DEPTH>::acc_bytes / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) s_misc[0] = 0;
+        __syncthreads();
+        run_class(std::false_type{}, cls);
     }
 #ifdef PROJ_STAMPS
     st_t2 = __builtin_amdgcn_s_memtime();
