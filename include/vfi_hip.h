@@ -64,6 +64,18 @@ int vfi_filterinterp_backward_ori(const float* input1, const float* input2, cons
                                   vfi_strides s1, vfi_strides s2, vfi_strides s3,
                                   vfi_stream_t stream);
 
+/* The same forward for SEVERAL flows over one image and one filter: outputs[t] = the function above with
+ * input2 = flows[t], t < nflows (bit for bit).  This is what DAIN_slowmotion does per direction: FilterInterpolate_ctx
+ * (networks/DAIN_slowmotion.py:167-183, 311-317) warps the same context tensor with the same filter once per time
+ * offset.  With filter_channels == 16 one launch stages ONE window per tile and channel for up to three flows (a third
+ * of the image traffic per output; more flows go in groups of three and two); other filter sizes are single launches.
+ * flows / outputs: HOST arrays of nflows device pointers; every flow has strides s2, every output s1. */
+int vfi_filterinterp_forward_ori_multi(const float* input1, const float* const* flows, const float* input3,
+                                       float* const* outputs, int nflows,
+                                       int batch, int channel, int h, int w, int filter_channels,
+                                       vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                       vfi_stream_t stream);
+
 /* fp16 STORAGE, fp32 arithmetic (BASELINE.json configs[2]): input1 and output are IEEE
  * half tensors (strides in half elements), flow and filter stay float32.  The result is the fp32
  * result of the function above on the widened inputs, rounded to half once; the LDS-staged path

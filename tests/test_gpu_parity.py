@@ -1422,3 +1422,56 @@ def test_projection_workspace_api_and_graph_replay_after_growth(torch_mod, cabi,
     assert cabi.flowprojection_forward(gflow, count, out, 1) == 0
     torch.cuda.synchronize()
     assert np.array_equal(cpu(count), rcount) and np.array_equal(cpu(out), ref)
+
+
+@pytest.mark.parametrize("B,C,H,W,nt", [(1, 5, 40, 200, 3), (2, 3, 33, 70, 2), (1, 7, 64, 130, 4), (1, 4, 20, 66, 5), (1, 3, 17, 64, 1)])
+def test_filterinterp_multi_flow(torch_mod, cabi, oracle, B, C, H, W, nt):
+    """vfi_filterinterp_forward_ori_multi: one image, one filter, nt flows -> nt outputs, each bit for bit the single-flow
+    op (and the oracle): scaled copies of one field as in a slow-motion step, an unrelated field, invalid regions."""
+    torch = torch_mod
+    rng = np.random.default_rng(B * 1000 + W)
+    img = rng.standard_normal((B, C, H, W)).astype(f32)
+    filt = rng.random((B, 16, H, W), dtype=f32)
+    base = smooth_flow(rng, B, H, W, 6.0)
+    flows = [(base * f32((t + 1) / (nt + 1))).astype(f32) for t in range(nt)]
+    if nt >= 3:
+        flows[-1] = (rng.standard_normal((B, 2, H, W)) * 9.0).astype(f32)           # unrelated, rough
+        flows[0][:, :, : H // 2, : W // 3] = 1000.0                                  # copy-through region
+    gi, gk = gpu(torch, img), gpu(torch, filt)
+    gf = [gpu(torch, f) for f in flows]
+    outs = [torch.full((B, C, H, W), float("nan"), device="cuda:0") for _ in range(nt)]
+    assert cabi.filterinterp_forward_ori_multi(gi, gf, gk, outs) == 0
+    for t in range(nt):
+        single = torch.empty_like(gi)
+        assert cabi.filterinterp_forward_ori(gi, gf[t], gk, single) == 0
+        assert torch.equal(outs[t], single), t
+        assert np.array_equal(cpu(outs[t]), oracle.filterinterp_ori_fwd(img, flows[t], filt, fmad=1)), t
+    # other filter sizes go through the single-flow kernels
+    filt5 = rng.random((B, 25, H, W), dtype=f32)
+    outs5 = [torch.full((B, C, H, W), float("nan"), device="cuda:0") for _ in range(min(nt, 2))]
+    assert cabi.filterinterp_forward_ori_multi(gi, gf[:len(outs5)], gpu(torch, filt5), outs5) == 0
+    for t in range(len(outs5)):
+        assert np.array_equal(cpu(outs5[t]), oracle.filterinterp_ori_fwd(img, flows[t], filt5, fmad=1))
+
+
+def test_filterinterp_multi_flow_1080p(torch_mod, cabi, oracle):
+    """The slow-motion shape: 1152x1984, three time offsets of one projected flow, 196 channels (== three single
+    launches) and the fused.FilterInterpolate_ctx_all mirror."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import fused, synthetic as S
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    ctx = [S.context(1, 196, H, W, gen).cuda() for _ in range(2)]
+    filt = [S.filters(1, H, W, gen).cuda() for _ in range(2)]
+    base = [S.flow(1, H, W, 8.0, gen, "smooth") for _ in range(2)]
+    offs = [[(base[d] * (2.0 * t)).contiguous().cuda() for t in (0.25, 0.5, 0.75)] for d in range(2)]
+    pairs = fused.FilterInterpolate_ctx_all(ctx[0], ctx[1], offs, filt)
+    single = torch.empty_like(ctx[0])
+    for t in range(3):
+        for d in range(2):
+            assert cabi.filterinterp_forward_ori(ctx[d], offs[d][t], filt[d], single) == 0
+            assert torch.equal(pairs[t][d], single), (t, d)
+    sel = [0, 97, 195]
+    ref = oracle.filterinterp_ori_fwd(ctx[0][:, sel].cpu().numpy(), offs[0][2].cpu().numpy(), filt[0].cpu().numpy(), fmad=1, nthreads=8)
+    assert np.array_equal(cpu(pairs[2][0][:, sel]), ref)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vfi_filterinterp_forward_ori": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_backward_ori": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_forward_ori_f16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_filterinterp_forward_ori_multi": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_filterinterp_forward_defor": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides,
                                        Strides, _p],
     "vfi_filterinterp_backward_defor": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides,
@@ -102,6 +103,10 @@ def _st(t):
     return Strides(t.stride(0), t.stride(1), t.stride(2))
 
 
+def _st_tuple(t):
+    return (t.stride(0), t.stride(1), t.stride(2), t.stride(3))
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -146,6 +151,23 @@ def filterinterp_forward_ori(input1, input2, input3, output, direct=False):
         fn = lib().vfi_filterinterp_forward_ori_direct if direct else lib().vfi_filterinterp_forward_ori
         return _finish(fn(_ptr(input1), _ptr(input2), _ptr(input3), _ptr(output), b, c, h, w, input3.size(1),
                           _st(input1), _st(input2), _st(input3), _stream(input1)))
+
+
+def filterinterp_forward_ori_multi(input1, flows, input3, outputs):
+    """outputs[t] = FilterInterpolation(input1, flows[t], input3): the time offsets of a slow-motion step in one launch."""
+    n = len(flows)
+    if n == 0 or len(outputs) != n:
+        return 1
+    for fl, out in zip(flows, outputs):
+        if _fi_checks(input1, fl, input3, out) is None or _st_tuple(fl) != _st_tuple(flows[0]) or _st_tuple(out) != _st_tuple(input1):
+            return 1
+        _dev(fl), _dev(out)
+    b, c, h, w = input1.shape
+    fp = (ctypes.c_void_p * n)(*[fl.data_ptr() for fl in flows])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outputs])
+    with torch.cuda.device(_dev(input1)):
+        return _finish(lib().vfi_filterinterp_forward_ori_multi(_ptr(input1), fp, _ptr(input3), op, n, b, c, h, w, input3.size(1),
+                                                                _st(input1), _st(flows[0]), _st(input3), _stream(input1)))
 
 
 def filterinterp_forward_ori_f16(input1, input2, input3, output, direct=False):

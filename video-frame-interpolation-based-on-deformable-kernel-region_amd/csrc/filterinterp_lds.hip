@@ -217,21 +217,35 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const int x = txi * FI_TW + (tid & (FI_TW - 1));
     const int y0 = tyi * FI_TH + (tid >> 6);
 
-    // ---- this thread's pixels: flow, validity, window origin, blend weights
+    // ---- this thread's pixels: flow, validity, window origin, blend weights.  The 16 filter taps of each pixel are
+    // fetched in the same round trip as its flow (they do not depend on it: a pixel the flow then declares invalid
+    // has loaded them for nothing) -- one dependent HBM round trip less before the first window can be staged,
+    // which is what a 3-channel launch consists of.
     FiPixel px[FI_PX];
     int L[FI_PX], T[FI_PX];
     int bx_lo = INT_MAX, by_lo = INT_MAX, bx_hi = INT_MIN, by_hi = INT_MIN;
+    float fxv[FI_PX], fyv[FI_PX];
 #pragma unroll
     for (int p = 0; p < FI_PX; ++p) {
         const int y = y0 + p * FI_PASS_ROWS;
         px[p].inimg = x < w && y < h;
         px[p].pix = (unsigned)(y * (int)s1.h + x);
-        float fx = 0.0f, fy = 0.0f;
+        fxv[p] = fyv[p] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) px[p].f[k] = 0.0f;
         if (px[p].inimg) {
             const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
-            fx = flow[0];
-            fy = flow[s2.c];
+            fxv[p] = flow[0];
+            fyv[p] = flow[s2.c];
+            const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) px[p].f[k] = fpx[(int64_t)k * s3.c];
         }
+    }
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p) {
+        const int y = y0 + p * FI_PASS_ROWS;
+        const float fx = fxv[p], fy = fyv[p];
         const float x2 = (float)x + fx;
         const float y2 = (float)y + fy;
         px[p].valid = px[p].inimg && fi_valid(fx, fy, x2, y2, w, h);
@@ -265,19 +279,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const int pitch = (bw + 31) & ~31;                      // LDS row pitch: a multiple of the 32 banks
     const int n = pitch * bh;                               // <= (w+33)*(h+2): fits int for any real frame
 
-    // ---- the 16 filter taps of each pixel
 #pragma unroll
-    for (int p = 0; p < FI_PX; ++p) {
-        px[p].lbase = (T[p] - by0) * pitch + (L[p] - bx0);
-        if (px[p].valid) {
-            const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)(y0 + p * FI_PASS_ROWS) * s3.h + x;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) px[p].f[k] = fpx[(int64_t)k * s3.c];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) px[p].f[k] = 0.0f;
-        }
-    }
+    for (int p = 0; p < FI_PX; ++p) px[p].lbase = (T[p] - by0) * pitch + (L[p] - bx0);
 
     const float* img = in1 + (int64_t)b * s1.b;
     float* dst = out + (int64_t)b * s1.b;

@@ -1,0 +1,334 @@
+// filterinterp_multi.hip -- FilterInterpolation (_ori, fs == 4) forward of ONE image with SEVERAL flows at once.
+//
+// DAIN_slowmotion warps the same 196-channel context tensor with the same filter once per time offset
+// (networks/DAIN_slowmotion.py:167-183 calls FilterInterpolate_ctx, :311-317, for t = 0.25, 0.5, 0.75: three
+// FilterInterpolationModule calls per direction that differ in the flow only).  Each of those calls streams the
+// whole tensor: the single-flow kernel (filterinterp_lds.hip) sits on the HBM ceiling, because a tile's window
+// rows drag in the 128-byte lines they share with the neighbouring tiles (profiles/README.md: 1.8 x the
+// algorithmic bytes leave the memory side).  Here a tile stages ONE window per channel -- the bounding box of the
+// taps of all NT flows; the flows of a slow-motion step are scaled copies of each other, so it is only a few
+// pixels larger than each flow's own window -- and produces NT outputs from it.  Per output: a third of the window
+// traffic, the same LDS reads and arithmetic.  Semantics per output: filterinterpolation_cuda_kernel.cu:2692-2823,
+// bit for bit the single-flow kernel's (same taps, same order).
+//
+// Tiling, LDS-DMA ring, counted vmcnt and tile -> XCD grouping: exactly filterinterp_lds.hip (see there); a thread
+// owns two pixels, each with NT (validity, window address, blend weights) and one set of 16 filter taps.
+#include "filterinterp_dev.h"
+
+#include <limits.h>
+
+namespace vfi {
+
+#define FM_TW 64
+#define FM_TH 16
+#define FM_PX 2
+#define FM_THREADS (FM_TW * FM_TH / FM_PX)          // 512
+#define FM_PASS_ROWS (FM_TH / FM_PX)
+#define FM_HDR 16
+#define FM_RING_FLOATS 15984                        // with the header: 64,000 B
+#define FM_RMAX 5
+#define FM_KTOP 15
+#define FM_XCDS 8
+#define FM_MAXT 3                                   // flows per launch (4 spills inside the channel loop at 128 registers)
+
+typedef __attribute__((address_space(3))) void* fm_lptr_t;
+
+struct FmPtrs { const float* flow[FM_MAXT]; float* out[FM_MAXT]; };
+struct FmWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
+template <int NT> struct FmPixel {
+    bool inimg;
+    unsigned pix;           // element offset of the pixel inside an image plane
+    float f[16];
+    bool valid[NT];
+    float alpha[NT], beta[NT];
+    int lbase[NT];          // LDS index of the 4x4 window origin of flow t inside the staged window
+};
+
+template <int K>
+__device__ __forceinline__ void fm_wait_windows(int younger_groups) {
+    switch (younger_groups) {
+    case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K) : "memory"); break;
+    }
+}
+
+template <int K, int NT>
+__device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
+                                                int c_begin, int c_end, int tid, const FmWindow& win,
+                                                const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring, int R) {
+    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+    // staged element e = tid + k * FM_THREADS, row pitch a multiple of the 32 LDS banks, borders replicated while
+    // staging, pad elements out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + k * FM_THREADS;
+        const int r = e / win.pitch;
+        const int col = e - r * win.pitch;
+        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+        goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
+    }
+    const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
+    constexpr int NP = K * FM_THREADS;
+    const int D = R - 1;
+    auto issue = [&](int c, int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
+        float* l = ring + slot * NP + tid;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fm_lptr_t)(l + k * FM_THREADS), 4, goff[k], 0, 0, 0);
+    };
+    auto compute = [&](int c, int slot) {
+        const float* base = ring + slot * NP;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // a wave-uniform descriptor of output plane (t, c) + the pixel's 32-bit byte offset: no 64-bit vector
+            // addresses (2 x NT of them, kept across the channel loop, do not fit the 128 registers)
+            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + boff + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < FM_PX; ++p) {
+                if (px[p].valid[t]) {
+                    const float* tp = base + px[p].lbase[t];
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[r * 4 + k] = tp[r * win.pitch + k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fi4_pixel(v, px[p].f, px[p].alpha[t], px[p].beta[t])), oplane,
+                                                          (int)(px[p].pix * 4u), 0, 0);
+                }
+                // one pixel evaluation at a time: left to itself the scheduler hoists the LDS reads of all 2 x NT
+                // evaluations (16 registers each) above the arithmetic and spills inside the counted-vmcnt loop
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (c_begin >= c_end) return;
+    const int last = c_end - 1;
+    for (int j = 0; j < D; ++j)
+        if (c_begin + j <= last) issue(c_begin + j, j);
+    fm_wait_windows<K>(min(c_begin + D - 1, last) - c_begin);
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int c = c_begin; c <= last; ++c) {
+        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
+        compute(c, slot);
+        if (c < last) fm_wait_windows<K>(min(c + D, last) - (c + 1));
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    // copy-through of the invalid pixels (:2814-2818), outside the pipelined loop
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < FM_PX; ++p)
+            if (px[p].inimg && !px[p].valid[t])
+                for (int c = c_begin; c < c_end; ++c)
+                    ptr.out[t][boff + (int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+}
+
+template <int NT>
+__global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
+    const float* __restrict__ in1, FmPtrs ptr, const float* __restrict__ in3, int channel, int h, int w,
+    vfi_strides s1, vfi_strides s2, vfi_strides s3, int tiles_x, int tiles_y, int ntiles, int ch_per_group) {
+    __shared__ float lds[FM_HDR + FM_RING_FLOATS];
+    int* box = reinterpret_cast<int*>(lds);
+
+    // four horizontally consecutive tiles per XCD (filterinterp_lds.hip)
+    const int bid = blockIdx.x;
+    const int xs = bid % FM_XCDS, kk = bid / FM_XCDS;
+    const int tile = ((kk / 4) * FM_XCDS + xs) * 4 + (kk % 4);
+    if (tile >= ntiles) return;
+    const int b = tile / (tiles_x * tiles_y);
+    const int trem = tile - b * (tiles_x * tiles_y);
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int c_begin = blockIdx.y * ch_per_group;
+    const int c_end = min(channel, c_begin + ch_per_group);
+
+    const int tid = threadIdx.x;
+    const int x = txi * FM_TW + (tid & (FM_TW - 1));
+    const int y0 = tyi * FM_TH + (tid >> 6);
+
+    const int flow_bytes = ((int)s2.c + (h - 1) * (int)s2.h + w) * 4;           // (the host checked that these fit 31 bits)
+    const int filt_bytes = (15 * (int)s3.c + (h - 1) * (int)s3.h + w) * 4;
+    FmPixel<NT> px[FM_PX];
+    int L[FM_PX][NT], T[FM_PX][NT];
+    float fxv[FM_PX][NT], fyv[FM_PX][NT];
+    int bx_lo = INT_MAX, by_lo = INT_MAX, bx_hi = INT_MIN, by_hi = INT_MIN;
+#pragma unroll
+    for (int p = 0; p < FM_PX; ++p) {
+        const int y = y0 + p * FM_PASS_ROWS;
+        px[p].inimg = x < w && y < h;
+        px[p].pix = (unsigned)(y * (int)s1.h + x);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) px[p].f[k] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fxv[p][t] = fyv[p][t] = 0.0f;
+        if (px[p].inimg) {
+            // (buffer loads: a uniform descriptor per tensor, a 32-bit byte offset per pixel, the plane's offset scalar)
+            const int fo = (y * (int)s2.h + x) * 4, ko = (y * (int)s3.h + x) * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const auto fr = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.flow[t] + (int64_t)b * s2.b), 0, flow_bytes, 0x00020000);
+                fxv[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, fo, 0, 0));
+                fyv[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fr, fo, (int)s2.c * 4, 0));
+            }
+            const auto kr = __builtin_amdgcn_make_buffer_rsrc((void*)(in3 + (int64_t)b * s3.b), 0, filt_bytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) px[p].f[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kr, ko, k * (int)s3.c * 4, 0));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < FM_PX; ++p) {
+        const int y = y0 + p * FM_PASS_ROWS;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float fx = fxv[p][t], fy = fyv[p][t];
+            const float x2 = (float)x + fx;
+            const float y2 = (float)y + fy;
+            px[p].valid[t] = px[p].inimg && fi_valid(fx, fy, x2, y2, w, h);
+            const int ix = px[p].valid[t] ? (int)x2 : 0, iy = px[p].valid[t] ? (int)y2 : 0;
+            L[p][t] = ix - 1;                               // ix + 1 - fs/2, fs == 4
+            T[p][t] = iy - 1;
+            px[p].alpha[t] = x2 - (float)ix;
+            px[p].beta[t] = y2 - (float)iy;
+            if (px[p].valid[t]) {
+                bx_lo = min(bx_lo, L[p][t]); by_lo = min(by_lo, T[p][t]);
+                bx_hi = max(bx_hi, L[p][t] + 3); by_hi = max(by_hi, T[p][t] + 3);
+            }
+        }
+    }
+
+    // ---- bounding box of every tap of the tile, all flows
+    if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
+    __syncthreads();
+    {
+        const int x0 = wave_min_i32(bx_lo), y0w = wave_min_i32(by_lo);
+        const int x1 = wave_max_i32(bx_hi), y1 = wave_max_i32(by_hi);
+        if ((tid & 63) == 0 && x0 != INT_MAX) {
+            atomicMin(&box[0], x0); atomicMin(&box[1], y0w);
+            atomicMax(&box[2], x1); atomicMax(&box[3], y1);
+        }
+    }
+    __syncthreads();
+    const int bx0 = box[0], by0 = box[1];
+    const bool any_valid = bx0 != INT_MAX;
+    const int bw = any_valid ? box[2] - bx0 + 1 : 0;
+    const int bh = any_valid ? box[3] - by0 + 1 : 0;
+    const int pitch = (bw + 31) & ~31;
+    const int n = pitch * bh;
+#pragma unroll
+    for (int p = 0; p < FM_PX; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) px[p].lbase[t] = (T[p][t] - by0) * pitch + (L[p][t] - bx0);
+
+    const int64_t boff = (int64_t)b * s1.b;
+    const float* img = in1 + boff;
+    const int kmax = (n + FM_THREADS - 1) / FM_THREADS;
+    if (kmax > FM_KTOP) {
+        // window too large for LDS: gather from global memory (workgroup-uniform branch)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < FM_PX; ++p) {
+                float* dst = ptr.out[t] + boff;
+                if (px[p].valid[t]) {
+                    fi4_channels_direct(img, dst + px[p].pix, c_begin, c_end, s1.c, (int)s1.h, h, w, L[p][t], T[p][t], px[p].f,
+                                        px[p].alpha[t], px[p].beta[t]);
+                } else if (px[p].inimg) {
+                    for (int c = c_begin; c < c_end; ++c) dst[(int64_t)c * s1.c + px[p].pix] = img[(int64_t)c * s1.c + px[p].pix];
+                }
+            }
+        return;
+    }
+
+    const FmWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
+    float* ring = lds + FM_HDR;
+#define FM_RUN(K) fm_run_channels<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring, \
+                                         min(FM_RMAX, FM_RING_FLOATS / ((K) * FM_THREADS)))
+    if (kmax <= 2) FM_RUN(2);
+    else if (kmax == 3) FM_RUN(3);
+    else if (kmax == 4) FM_RUN(4);
+    else if (kmax == 5) FM_RUN(5);
+    else if (kmax == 6) FM_RUN(6);
+    else if (kmax == 7) FM_RUN(7);
+    else if (kmax == 8) FM_RUN(8);
+    else if (kmax <= 10) FM_RUN(10);
+    else if (kmax <= 12) FM_RUN(12);
+    else FM_RUN(15);
+#undef FM_RUN
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" int vfi_filterinterp_forward_ori(const float* input1, const float* input2, const float* input3,
+                                             float* output, int batch, int channel, int h, int w,
+                                             int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                             vfi_stream_t stream);
+
+extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const float* const* flows, const float* input3,
+                                                   float* const* outputs, int nflows, int batch, int channel, int h, int w,
+                                                   int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                                   vfi_stream_t stream) {
+    if (nflows <= 0 || !flows || !outputs || batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_channels <= 0)
+        return VFI_ERR_SHAPE;
+    if (!input1 || !input3) return VFI_ERR_SHAPE;
+    for (int t = 0; t < nflows; ++t)
+        if (!flows[t] || !outputs[t]) return VFI_ERR_SHAPE;
+    // more flows than one launch takes: groups of three, the rest as a pair or alone
+    if (nflows > FM_MAXT) {
+        for (int t0 = 0; t0 < nflows;) {
+            const int n = (nflows - t0 == FM_MAXT + 1) ? 2 : (nflows - t0 < FM_MAXT ? nflows - t0 : FM_MAXT);
+            const int err = vfi_filterinterp_forward_ori_multi(input1, flows + t0, input3, outputs + t0, n, batch, channel, h, w,
+                                                               filter_channels, s1, s2, s3, stream);
+            if (err != VFI_OK) return err;
+            t0 += n;
+        }
+        return VFI_OK;
+    }
+    // the shared-window kernel: fs == 4, 2 or 3 flows, in-plane byte offsets within 32 bits; anything else is the
+    // single-flow entry point once per flow (same results)
+    const bool staged = filter_channels == 16 && nflows >= 2 && nflows <= FM_MAXT && (int64_t)h * s1.h * 4 <= INT_MAX &&
+                        s2.c >= 0 && s3.c >= 0 && (s2.c + (int64_t)h * s2.h) * 4 <= INT_MAX && (15 * s3.c + (int64_t)h * s3.h) * 4 <= INT_MAX;
+    if (!staged) {
+        for (int t = 0; t < nflows; ++t) {
+            const int err = vfi_filterinterp_forward_ori(input1, flows[t], input3, outputs[t], batch, channel, h, w,
+                                                         filter_channels, s1, s2, s3, stream);
+            if (err != VFI_OK) return err;
+        }
+        return VFI_OK;
+    }
+    const int tiles_x = (w + FM_TW - 1) / FM_TW, tiles_y = (h + FM_TH - 1) / FM_TH;
+    const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
+    if (nt > (1 << 28)) return VFI_ERR_SHAPE;
+    const int ntiles = (int)nt;
+    const int per_xcd = (((ntiles + FM_XCDS - 1) / FM_XCDS) + 3) & ~3;          // whole groups of four tiles
+    // channel groups over blockIdx.y when that shortens the tail (filterinterp_lds.hip); every extra group re-reads
+    // the flows and the 16 filter planes
+    const int slots = device_cu_count() * 2;
+    int best_groups = 1;
+    double best_cost = 0.0;
+    for (int g = 1; g <= 8 && g <= channel; g *= 2) {
+        const double wgs = (double)ntiles * g;
+        const double tail = ceil(wgs / slots) * slots / wgs;
+        const double fixed = 64.0 + 8.0 * nflows, per_ch = 4.0 + 4.0 * nflows;
+        const double cost = tail * (fixed * g + per_ch * channel) / (fixed + per_ch * channel);
+        if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
+    }
+    const int ch_per_group = (channel + best_groups - 1) / best_groups;
+    const int groups = (channel + ch_per_group - 1) / ch_per_group;
+    FmPtrs ptr;
+    for (int t = 0; t < FM_MAXT; ++t) { ptr.flow[t] = flows[t < nflows ? t : 0]; ptr.out[t] = outputs[t < nflows ? t : 0]; }
+    const dim3 grid((unsigned)(per_xcd * FM_XCDS), (unsigned)groups, 1), block(FM_THREADS, 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    switch (nflows) {
+    case 2: hipLaunchKernelGGL(fi_forward_ori_multi<2>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group); break;
+    default: hipLaunchKernelGGL(fi_forward_ori_multi<3>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group); break;
+    }
+    return launch_status();
+}

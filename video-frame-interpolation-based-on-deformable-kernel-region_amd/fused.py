@@ -50,6 +50,19 @@ def FilterInterpolate(ref0, ref2, offset, filter, filter_size2, time_offset):
     return blend, out0, out2
 
 
+def FilterInterpolate_ctx_all(ctx0, ctx2, offsets, filter):
+    """`DAIN_slowmotion.FilterInterpolate_ctx` (networks/DAIN_slowmotion.py:311-317) for every time offset of a step at
+    once (the loop at :167-183 calls it once per t with the same context tensors and filters): offsets[d][t] is the
+    projected flow of direction d at time offset t.  Returns [(ctx0_offset_t, ctx2_offset_t) for t], each pair what
+    the reference's call returns -- from one launch per direction that stages every image window once."""
+    nt = len(offsets[0])
+    out0 = [torch.empty_like(ctx0) for _ in range(nt)]
+    out2 = [torch.empty_like(ctx2) for _ in range(nt)]
+    _check(cabi.filterinterp_forward_ori_multi(ctx0, list(offsets[0]), filter[0], out0), "filterinterp_forward_ori_multi")
+    _check(cabi.filterinterp_forward_ori_multi(ctx2, list(offsets[1]), filter[1], out2), "filterinterp_forward_ori_multi")
+    return list(zip(out0, out2))
+
+
 def warp(x, flo, align_corners=True):
     """`PWCDCNet.warp`."""
     out = torch.empty_like(x)
