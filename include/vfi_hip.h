@@ -297,6 +297,14 @@ int vfi_pwc_warp_forward(const float* x, const float* flow, float* output,
                          vfi_strides sx, vfi_strides sf, vfi_strides so,
                          vfi_stream_t stream);
 
+/* PWCDCNet's warp feeding its correlation layer (PWCNet/PWCNet.py:244-247, 266-267, 282-283, 299-300):
+ * output[B,81,h,w] = correlation(input1, warp(input2, flow)) with pad 4, kernel 1, max displacement 4, strides 1 --
+ * vfi_pwc_warp_forward followed by vfi_correlation_forward, bit for bit, in one launch and without the warped
+ * tensor.  input1 / input2 / output dense NCHW, flow [B,2,h,w] with strides sf. */
+int vfi_pwc_warp_correlation_forward(const float* input1, const float* input2, const float* flow, float* output,
+                                     int batch, int channel, int h, int w, int align_corners,
+                                     vfi_strides sf, vfi_stream_t stream);
+
 /* frame boundary (demo_MiddleBury.py:280-318, 350-364, 370-388).
  * u8 -> planar: dst[b,c,y,x] = src[b, clamp(y - pad_top), clamp(x - pad_left), c] / 255 for the padded
  * frame (h + pad_top + pad_bottom) x (w + pad_left + pad_right); src is dense [B,h,w,3] uint8.

@@ -1475,3 +1475,40 @@ def test_filterinterp_multi_flow_1080p(torch_mod, cabi, oracle):
     sel = [0, 97, 195]
     ref = oracle.filterinterp_ori_fwd(ctx[0][:, sel].cpu().numpy(), offs[0][2].cpu().numpy(), filt[0].cpu().numpy(), fmad=1, nthreads=8)
     assert np.array_equal(cpu(pairs[2][0][:, sel]), ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 36, 62), (2, 19, 18, 31), (1, 8, 72, 124), (1, 3, 5, 7), (1, 196, 9, 13)])
+@pytest.mark.parametrize("align_corners", [True, False])
+def test_pwc_warp_correlation_fused(torch_mod, cabi, oracle, shape, align_corners):
+    """warp -> correlation of PWC-Net in one launch == the two launches == the oracle's two functions, bit for bit;
+    flows that leave the map (mask 0), land on its edge, and NaN-free rough fields."""
+    torch = torch_mod
+    B, C, H, W = shape
+    rng = np.random.default_rng(C * 100 + W)
+    f1 = rng.standard_normal(shape).astype(f32)
+    f2 = rng.standard_normal(shape).astype(f32)
+    flo = (rng.standard_normal((B, 2, H, W)) * 2.5).astype(f32)
+    flo[:, :, 0, :] = 50.0                                            # a row of samples far outside
+    flo[:, 0, :, 0] = 0.0                                             # integer positions on the edge
+    fused_out = cabi.pwc_warp_correlation_forward(gpu(torch, f1), gpu(torch, f2), gpu(torch, flo), align_corners)
+    warped = torch.empty((B, C, H, W), device="cuda:0")
+    assert cabi.pwc_warp_forward(gpu(torch, f2), gpu(torch, flo), warped, align_corners) == 0
+    two = cabi.correlation_forward(gpu(torch, f1), warped, 4, 1, 4, 1, 1)
+    assert torch.equal(fused_out, two)
+    ref = oracle.correlation_fwd(f1, oracle.pwc_warp(f2, flo, align_corners, fmad=1), 4, 1, 4, 1, 1, order=1, fmad=1)
+    assert np.array_equal(cpu(fused_out), ref)
+
+
+def test_pwc_warp_correlation_pyramid_1080p(torch_mod, cabi, oracle):
+    """the four warped levels of a 1080p pyramid (32@288x496 ... 128@36x62), fused == two launches"""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import fused, synthetic as S
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    for f1, f2 in S.correlation_features(1, H, W, gen)[1:]:
+        h, w = f1.shape[2:]
+        flo = (torch.randn((1, 2, h, w), generator=gen) * 1.5).cuda()
+        a = fused.warp_corr(f1.cuda(), f2.cuda(), flo, one_launch=True)
+        b = fused.warp_corr(f1.cuda(), f2.cuda(), flo)
+        assert torch.equal(a, b), tuple(f1.shape)

@@ -161,6 +161,27 @@ def main():
                 return o * m
             tot_t += timed(torch_warp, args.iters * 5)
         print("glue  PWC warp, 5 levels       %8.4f ms | torch grid_sample x2 + mask ops %8.4f ms" % (tot_f, tot_t), flush=True)
+        # one PWC direction: coarsest level plain correlation, four levels warp -> correlation; two launches each vs one
+        t2 = t1 = 0.0
+        feats = [(a.to(dev), b2.to(dev)) for a, b2 in S.correlation_features(1, h, w, gen)]
+        for li, (a, b2) in enumerate(feats):
+            if li == 0:
+                ms0 = timed(lambda: cabi.correlation_forward(a, b2, 4, 1, 4, 1, 1), args.iters * 5)
+                t2 += ms0
+                t1 += ms0
+                continue
+            fl = (torch.randn((1, 2, a.shape[2], a.shape[3]), generator=gen) * 1.5).to(dev)
+            wo = torch.empty_like(b2)
+
+            def two():
+                cabi.pwc_warp_forward(b2, fl, wo, True)
+                return cabi.correlation_forward(a, wo, 4, 1, 4, 1, 1)
+            m2 = timed(two, args.iters * 5)
+            m1 = timed(lambda: cabi.pwc_warp_correlation_forward(a, b2, fl, True), args.iters * 5)
+            print("glue  level C=%-3d %4dx%-4d warp + correlation %8.4f ms | fused %8.4f ms" % (a.shape[1], a.shape[2], a.shape[3], m2, m1), flush=True)
+            t2 += m2
+            t1 += m1
+        print("glue  one PWC direction (5 correlations, 4 warps): %8.4f ms in 9 launches | %8.4f ms in 5" % (t2, t1), flush=True)
         u8 = torch.randint(0, 256, (1, args.height, args.width, 3), dtype=torch.uint8, generator=gen).to(dev)
         pad = fused.padding_for(args.height, args.width)
         x = torch.empty((1, 3, h, w), device=dev)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vfi_filterinterp_blend_forward": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, Strides, Strides,
                                        Strides, Strides, _p],
     "vfi_pwc_warp_forward": [_p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
+    "vfi_pwc_warp_correlation_forward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, _p],
     "vfi_frame_u8_to_planar": [_p, _p, _i, _i, _i, _i, _i, _i, _i, Strides, _p],
     "vfi_planar_to_frame_u8": [_p, _p, _i, _i, _i, _i, _i, Strides, _p],
     "vfi_frame_error_sums": [_p, _p, ctypes.c_int64, _p, _p],
@@ -547,6 +548,22 @@ def pwc_warp_forward(x, flow, output, align_corners=True):
     with torch.cuda.device(_dev(x)):
         return _finish(lib().vfi_pwc_warp_forward(_ptr(x), _ptr(flow), _ptr(output), b, c, h, w, int(bool(align_corners)),
                                                   _st(x), _st(flow), _st(output), _stream(x)))
+
+
+def pwc_warp_correlation_forward(input1, input2, flow, align_corners=True):
+    """correlation(input1, warp(input2, flow)) of PWC-Net (pad 4, k 1, md 4, strides 1) in one launch; returns [B,81,h,w]."""
+    input1, input2 = input1.contiguous(), input2.contiguous()
+    b, c, h, w = input1.shape
+    if tuple(input2.shape) != (b, c, h, w) or tuple(flow.shape) != (b, 2, h, w) or flow.stride(3) != 1:
+        raise RuntimeError("pwc_warp_correlation_forward: shape mismatch")
+    _dev(input2), _dev(flow)
+    output = torch.empty((b, 81, h, w), dtype=torch.float32, device=input1.device)
+    with torch.cuda.device(_dev(input1)):
+        err = _finish(lib().vfi_pwc_warp_correlation_forward(_ptr(input1), _ptr(input2), _ptr(flow), _ptr(output), b, c, h, w,
+                                                             int(bool(align_corners)), _st(flow), _stream(input1)))
+    if err != 0:
+        raise RuntimeError("CUDA call failed")
+    return output
 
 
 def frame_u8_to_planar(src_hwc, dst, pad_left, pad_right, pad_top, pad_bottom):

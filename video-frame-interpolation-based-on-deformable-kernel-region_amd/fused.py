@@ -70,6 +70,17 @@ def warp(x, flo, align_corners=True):
     return out
 
 
+def warp_corr(c1, c2, flo, align_corners=True, one_launch=False):
+    """`self.corr(c1, self.warp(c2, flo))` of PWCDCNet.forward (PWCNet/PWCNet.py:244-247 ...); the reference applies
+    its LeakyReLU to the result afterwards.  Default: the warp kernel, then the correlation kernel.  one_launch=True:
+    vfi_pwc_warp_correlation_forward, which never materialises the warped tensor -- same bits, but measured SLOWER on
+    MI355X at PWC-Net's sizes (0.33 vs 0.15 ms for the five levels of a 1080p pair): every tile re-forms the bilinear
+    samples of its 4-pixel halo (3.75 x the taps), which costs more than the 2 x 18 MB round trip it saves."""
+    if one_launch:
+        return cabi.pwc_warp_correlation_forward(c1, c2, flo, align_corners)
+    return cabi.correlation_forward(c1, warp(c2, flo, align_corners), 4, 1, 4, 1, 1)
+
+
 def padding_for(height, width):
     """(left, right, top, bottom) of `demo_MiddleBury.py:294-310`: next multiple of 128, or 32 each side."""
     def one(n):
