@@ -73,6 +73,12 @@ struct FiPixel {
     unsigned pix;           // element offset of the pixel inside an image plane
     float f[16];
 };
+// Optional epilogue (DAIN.FilterInterpolate, networks/DAIN.py:560-573 / DAIN_slowmotion.py:324-335): this launch is the
+// second of the pair; besides its own result v it writes blend = other * w0 + v * w2 (products rounded separately, as
+// torch's three elementwise ops), `other` being the first launch's output.  For frames only (FI_BLEND_MAXC channels at
+// most): the partner value is loaded inside the channel loop, which would cost a deep ring its depth.
+#define FI_BLEND_MAXC 4
+struct FiBlend { const float* other; float* out; float w0, w2; };
 
 // s_waitcnt vmcnt(G*K): everything but the youngest G staged windows (K DMA loads each) has landed.
 // The pixel stores of the compute phases sit in the same in-order counter; not counting them
@@ -88,11 +94,11 @@ __device__ __forceinline__ void fi_wait_windows(int younger_groups) {
 }
 
 // Channel loop of one workgroup: K staged elements per thread and channel, ring of R slots.
-template <int K>
+template <int K, bool BLEND>
 __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
                                                 int c_begin, int c_end, int tid, const FiWindow& win,
                                                 const FiPixel (&px)[FI_PX], float* __restrict__ ring, int R,
-                                                int flags) {
+                                                int flags, const FiBlend& bl) {
     static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
     // Element e = tid + k*FI_THREADS of the staged window, row-major with row pitch `pitch` = bw
     // rounded up to a multiple of 32 floats: with the pitch a multiple of the 32 LDS banks a tap's
@@ -135,7 +141,16 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.pitch + k];
-                o[px[p].pix] = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+                const float val = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+                o[px[p].pix] = val;
+                if constexpr (BLEND) {
+                    // (a load inside the counted-vmcnt loop drains the ring -- harmless here: a frame's three windows
+                    //  were all issued before the loop)
+                    const float* bi = bl.other + (int64_t)c * cs;
+                    const float q0 = bi[px[p].pix] * bl.w0, q2 = val * bl.w2;
+                    float* bo = bl.out + (int64_t)c * cs;               // (wave-uniform plane pointer + 32-bit pixel offset)
+                    bo[px[p].pix] = q0 + q2;
+                }
             }
         }
     };
@@ -162,15 +177,23 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
 #pragma unroll
     for (int p = 0; p < FI_PX; ++p)
         if (px[p].inimg && !px[p].valid)
-            for (int c = c_begin; c < c_end; ++c) out[(int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+            for (int c = c_begin; c < c_end; ++c) {
+                const float val = img[(int64_t)c * cs + px[p].pix];
+                out[(int64_t)c * cs + px[p].pix] = val;
+                if constexpr (BLEND) {
+                    const float q0 = bl.other[(int64_t)c * cs + px[p].pix] * bl.w0, q2 = val * bl.w2;
+                    bl.out[(int64_t)c * cs + px[p].pix] = q0 + q2;
+                }
+            }
 }
 
 // two 512-thread workgroups per CU (4 waves per SIMD): at most 128 VGPRs
+template <bool BLEND>
 __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3,
-    int tiles_x, int tiles_y, int ntiles, int per_xcd, int ch_per_group, int flags) {
+    int tiles_x, int tiles_y, int ntiles, int per_xcd, int ch_per_group, int flags, FiBlend blend) {
     // ONE LDS array (a second __shared__ object beside an LDS-DMA target makes hipcc drain vmcnt
     // before LDS reads): 16-float header holding the bounding box, then the window ring
     __shared__ float lds[FI_HDR + FI_RING_FLOATS];
@@ -284,6 +307,8 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
     const float* img = in1 + (int64_t)b * s1.b;
     float* dst = out + (int64_t)b * s1.b;
+    const FiBlend bl{blend.other ? blend.other + (int64_t)b * s1.b : nullptr, blend.out ? blend.out + (int64_t)b * s1.b : nullptr,
+                     blend.w0, blend.w2};
 
     const int kmax = (n + FI_THREADS - 1) / FI_THREADS;     // workgroup-uniform
     if (kmax > FI_KTOP) {
@@ -296,14 +321,19 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
             } else if (px[p].inimg) {
                 for (int c = c_begin; c < c_end; ++c) dst[(int64_t)c * s1.c + px[p].pix] = img[(int64_t)c * s1.c + px[p].pix];
             }
+            if (BLEND && px[p].inimg)                           // (this thread wrote dst[...] itself: it reads its own stores)
+                for (int c = c_begin; c < c_end; ++c) {
+                    const float q0 = bl.other[(int64_t)c * s1.c + px[p].pix] * bl.w0, q2 = dst[(int64_t)c * s1.c + px[p].pix] * bl.w2;
+                    bl.out[(int64_t)c * s1.c + px[p].pix] = q0 + q2;
+                }
         }
         return;
     }
 
     const FiWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FI_HDR;
-#define FI_RUN(K) fi_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
-                                     min((flags >> 8) ? (flags >> 8) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags)
+#define FI_RUN(K) fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
+                                     min((flags >> 8) ? (flags >> 8) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
     if (kmax <= 2) FI_RUN(2);
     else if (kmax == 3) FI_RUN(3);
     else if (kmax == 4) FI_RUN(4);
@@ -332,10 +362,8 @@ extern "C" void vfi_dev_filterinterp(int flags, int groups) { g_fi_flags = flags
 #endif
 
 // returns -1 when this path does not apply (caller uses the direct kernel)
-extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float* input2, const float* input3,
-                                                 float* output, int batch, int channel, int h, int w,
-                                                 vfi_strides s1, vfi_strides s2, vfi_strides s3,
-                                                 vfi_stream_t stream) {
+static int forward_ori_lds(const float* input1, const float* input2, const float* input3, float* output, int batch, int channel,
+                           int h, int w, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_stream_t stream, FiBlend blend) {
     // byte offsets inside a plane are 32-bit in the kernel
     if ((int64_t)h * s1.h * 4 > INT_MAX) return -1;
     const int tiles_x = (w + FI_TW - 1) / FI_TW, tiles_y = (h + FI_TH - 1) / FI_TH;
@@ -358,6 +386,7 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
         if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
     }
     if (g_fi_groups > 0) best_groups = g_fi_groups < channel ? g_fi_groups : channel;
+    if (blend.out) best_groups = 1;                         // (the blend epilogue keeps a pixel's channels in one workgroup)
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
 
@@ -368,7 +397,28 @@ extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float
         grid_x = ((ngroups + FI_XCDS - 1) / FI_XCDS) * FI_XCDS * GW * GH;
     }
     const dim3 grid((unsigned)grid_x, (unsigned)groups, 1);
-    hipLaunchKernelGGL(fi_forward_ori_lds, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
-                       input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags);
+    if (blend.out)
+        hipLaunchKernelGGL(fi_forward_ori_lds<true>, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
+    else
+        hipLaunchKernelGGL(fi_forward_ori_lds<false>, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
     return launch_status();
+}
+
+extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float* input2, const float* input3,
+                                                 float* output, int batch, int channel, int h, int w,
+                                                 vfi_strides s1, vfi_strides s2, vfi_strides s3,
+                                                 vfi_stream_t stream) {
+    return forward_ori_lds(input1, input2, input3, output, batch, channel, h, w, s1, s2, s3, stream, FiBlend{nullptr, nullptr, 0.0f, 0.0f});
+}
+
+// internal: the second launch of DAIN.FilterInterpolate with the blend as its epilogue -- besides output it writes
+// blend = other * w0 + output * w2; other / blend have input1's strides; channel <= FI_BLEND_MAXC.  -1: not applicable.
+extern "C" int vfi_filterinterp_forward_ori_lds_blend(const float* input1, const float* input2, const float* input3,
+                                                       float* output, const float* other, float* blend, float w0, float w2,
+                                                       int batch, int channel, int h, int w,
+                                                       vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_stream_t stream) {
+    if (channel > FI_BLEND_MAXC || !other || !blend) return -1;
+    return forward_ori_lds(input1, input2, input3, output, batch, channel, h, w, s1, s2, s3, stream, FiBlend{other, blend, w0, w2});
 }

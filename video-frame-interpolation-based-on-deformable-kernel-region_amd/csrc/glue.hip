@@ -329,6 +329,11 @@ __global__ __launch_bounds__(256) void frame_ssim_sums(const unsigned char* __re
 
 using namespace vfi;
 
+extern "C" int vfi_filterinterp_forward_ori_lds_blend(const float* input1, const float* input2, const float* input3,
+                                                       float* output, const float* other, float* blend, float w0, float w2,
+                                                       int batch, int channel, int h, int w,
+                                                       vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_stream_t stream);
+
 extern "C" int vfi_filterinterp_blend_forward(const float* ref0, const float* ref2, const float* flow0, const float* flow2,
                                                const float* filt0, const float* filt2, float* blend, float* out0,
                                                float* out2, int batch, int channel, int h, int w, int filter_channels,
@@ -342,6 +347,10 @@ extern "C" int vfi_filterinterp_blend_forward(const float* ref0, const float* re
         // input's strides), then the blend
         int err = vfi_filterinterp_forward_ori(ref0, flow0, filt0, out0, batch, channel, h, w, 16, s_ref, s_flow, s_filt, stream);
         if (err != VFI_OK) return err;
+        // the blend as the second launch's epilogue (3-channel frames); else a launch of its own
+        err = vfi_filterinterp_forward_ori_lds_blend(ref2, flow2, filt2, out2, out0, blend, w0, w2, batch, channel, h, w, s_ref, s_flow,
+                                                     s_filt, stream);
+        if (err != -1) return err;
         err = vfi_filterinterp_forward_ori(ref2, flow2, filt2, out2, batch, channel, h, w, 16, s_ref, s_flow, s_filt, stream);
         if (err != VFI_OK) return err;
         hipLaunchKernelGGL(fi_blend_only, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream, out0,
