@@ -64,12 +64,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
-    const float* __restrict__ gout, float* g1, float* g2, float* g3,
+    const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g2, float* g3,
     int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    const float gscale = gradacc_scale(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -82,14 +83,14 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float alpha = x2 - (float)ix;
     const float beta = y2 - (float)iy;
     const float* img = in1 + (int64_t)b * s1.b;
-    float* gimg = g1 + (int64_t)b * s1.b;
+    unsigned long long* gimg = acc + (int64_t)b * channel * h * w;       // dense [b][c][y][x] fixed-point sums
     const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
     float* gfpx = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
     const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
     float gx = 0.0f, gy = 0.0f;
     for (int c = 0; c < channel; ++c) {
         const float* p = img + (int64_t)c * s1.c;
-        float* gp = gimg + (int64_t)c * s1.c;
+        unsigned long long* gp = gimg + (int64_t)c * h * w;
         const float g = gpx[(int64_t)c * s1.c];
         const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
                               g * (1.0f - alpha) * beta,          g * alpha * beta };
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
                     const int64_t o = ro + clampi(i, 0, w - 1);
                     const int64_t k = (int64_t)((j - T) * fs + (i - L)) * s3.c;
                     const float pv = p[o], fv = fpx[k];
-                    // image gradient: other pixels hit the same cell -> atomic.  The filter
-                    // gradient cell belongs to this thread alone (index is this pixel's own),
-                    // so a plain read-modify-write is equivalent to the reference's atomicAdd.
-                    atomicAdd(&gp[o], qg[quad] * fv);
+                    // image gradient: other pixels hit the same cell -> order-free fixed-point atomic (vfi_common.h).
+                    // The filter gradient cell belongs to this thread alone (index is this pixel's own), so a plain
+                    // read-modify-write is equivalent to the reference's atomicAdd.
+                    gradacc_add(&gp[(int64_t)clampi(j, 0, h - 1) * w + clampi(i, 0, w - 1)], qg[quad] * fv, gscale);
                     gfpx[k] += qg[quad] * pv;
                     acc = fmaf(pv, fv, acc);
                 }
@@ -242,12 +243,14 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_defor(
 template <int VARIANT>
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
-    const float* __restrict__ in4, const float* __restrict__ gout, float* g1, float* g2, float* g3, float* g4,
+    const float* __restrict__ in4, const float* __restrict__ gout, unsigned long long* __restrict__ acc,
+    const int* __restrict__ hdr, float* g2, float* g3, float* g4,
     int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    const float gscale = gradacc_scale(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     const float alpha = x2 - (float)ix;
     const float beta = y2 - (float)iy;
     const float* img = in1 + (int64_t)b * s1.b;
-    float* gimg = g1 + (int64_t)b * s1.b;
+    unsigned long long* gimg = acc + (int64_t)b * channel * h * w;       // dense [b][c][y][x] fixed-point sums
     const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
     // VARIANT 2: the third input IS the offset field and g3 its gradient; no filter
     const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     float gx = 0.0f, gy = 0.0f;
     for (int c = 0; c < channel; ++c) {
         const float* p = img + (int64_t)c * s1.c;
-        float* gp = gimg + (int64_t)c * s1.c;
+        unsigned long long* gp = gimg + (int64_t)c * h * w;
         const float g = gpx[(int64_t)c * s1.c];
         const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
                               g * (1.0f - alpha) * beta,          g * alpha * beta };
@@ -308,15 +311,15 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
                 dX = fmaf(1.0f - phiY, vTR, dX);
                 dX = fmaf(-phiY, vBL, dX);
                 dX = fmaf(phiY, vBR, dX);
-                const int64_t o = (int64_t)cj * s1.h + ci;
+                const int64_t o = (int64_t)cj * w + ci;
                 if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
-                    atomicAdd(&gp[o], qg[quad]);
+                    gradacc_add(&gp[o], qg[quad], gscale);
                     q[quad] = q[quad] + v;
                     gopx[(int64_t)k * ocs] += g * kq[quad] * dY;
                     gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX;
                 } else {
                     const float wgt = fpx[(int64_t)k * s3.c];
-                    atomicAdd(&gp[o], qg[quad] * wgt);
+                    gradacc_add(&gp[o], qg[quad] * wgt, gscale);
                     gfpx[(int64_t)k * s3.c] += qg[quad] * v;
                     q[quad] = fmaf(v, wgt, q[quad]);
                     gopx[(int64_t)k * ocs] += g * kq[quad] * dY * wgt;
@@ -404,10 +407,15 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
     if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3)
         return VFI_ERR_SHAPE;
     const int fs = fi_filter_size(filter_channels);
+    unsigned long long* acc;
+    int* hdr;
+    int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    if (err != VFI_OK) return err;
     hipLaunchKernelGGL(fi_backward_ori, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3,
+                       input1, input2, input3, gradoutput, acc, hdr, gradinput2, gradinput3,
                        channel, h, w, fs, s1, s2, s3);
-    return launch_status();
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }
 
 extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* input1, const float* input2,
@@ -482,26 +490,30 @@ extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1,
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || filter_size <= 0) return VFI_ERR_SHAPE;
     if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3) return VFI_ERR_SHAPE;
     if (variant != VFI_DEFOR_NOFILTER && (!input4 || !gradinput4)) return VFI_ERR_SHAPE;
+    if (variant < 0 || variant > 2) return VFI_ERR_SHAPE;
     const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
     hipStream_t st = (hipStream_t)stream;
+    unsigned long long* acc;
+    int* hdr;
+    const int err = gradacc_begin(st, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    if (err != VFI_OK) return err;
     switch (variant) {
     case VFI_DEFOR_OFFSET:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
                            s1, s2, s3, s4);
         break;
     case VFI_DEFOR_REGION:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
                            s1, s2, s3, s4);
         break;
-    case VFI_DEFOR_NOFILTER:
+    default:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3, input3,
-                           gradoutput, gradinput1, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
                            s1, s2, s3, s3);
         break;
-    default:
-        return VFI_ERR_SHAPE;
     }
-    return launch_status();
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    return gradacc_finish(st, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }

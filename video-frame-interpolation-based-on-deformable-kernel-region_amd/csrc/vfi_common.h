@@ -75,6 +75,28 @@ inline dim3 pixel_grid(int w, int h, int batch) {
 // compute units of the CURRENT device (cached per device id)
 int device_cu_count();
 
+// Deterministic image gradients.  The reference scatters the image gradient of its warping layers with fp32 atomics
+// (filterinterpolation_cuda_kernel.cu:2890-2942, interpolation_cuda_kernel.cu:154-157): the sum depends on the order the
+// atomics arrive in, so two runs differ in the last bits.  Here every addend is scaled by ONE power of two per call
+// (2^36 over the largest |gradoutput| element: 2^10 of headroom for the tap weights, 2^16 addends per cell), rounded to
+// an integer and added with a 64-bit INTEGER atomic into a scratch plane; a last pass converts the exact integer sums
+// to float once and adds them to the caller's (zero-filled) gradient.  Order-free, hence reproducible bit for bit.
+//   host:   gradacc_begin (zeroes the scratch, finds the largest |gradoutput|)  ->  the backward kernel  ->  gradacc_finish
+//   device: gradacc_scale(hdr) once per thread, gradacc_add(cell, addend, scale) per addend; cells are indexed densely
+//           [b][c][y][x] whatever the strides of the gradient tensor.
+__device__ __forceinline__ float gradacc_scale(const int* __restrict__ hdr) {
+    int e = 0;
+    (void)frexpf(__int_as_float(hdr[0]), &e);
+    return ldexpf(1.0f, max(-100, min(100, 36 - e)));
+}
+__device__ __forceinline__ void gradacc_add(unsigned long long* cell, float v, float scale) {
+    atomicAdd(cell, (unsigned long long)__float2ll_rn(v * scale));
+}
+int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
+                  unsigned long long** acc, int** hdr);
+int gradacc_finish(hipStream_t st, const unsigned long long* acc, const int* hdr, float* g1, int batch, int channel, int h, int w,
+                   vfi_strides s1);
+
 inline int launch_status() {
     return hipGetLastError() == hipSuccess ? VFI_OK : VFI_ERR_LAUNCH;
 }

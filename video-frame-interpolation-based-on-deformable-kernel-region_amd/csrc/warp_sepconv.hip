@@ -43,11 +43,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_forward(
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
-    float* g1, float* g2, int channel, int h, int w, vfi_strides s1, vfi_strides s2) {
+    unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g2, int channel, int h, int w, vfi_strides s1,
+    vfi_strides s2) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    const float gscale = gradacc_scale(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -58,20 +60,21 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
     const int R = min(L + 1, w - 1), Bm = min(T + 1, h - 1);
     const float alpha = x2 - (float)L, beta = y2 - (float)T;
     const float* img = in1 + (int64_t)b * s1.b;
-    float* gimg = g1 + (int64_t)b * s1.b;
+    unsigned long long* gimg = acc + (int64_t)b * channel * h * w;       // dense [b][c][y][x] fixed-point sums (vfi_common.h)
     const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
     const int64_t oT = (int64_t)T * s1.h, oB = (int64_t)Bm * s1.h;
+    const int64_t aT = (int64_t)T * w, aB = (int64_t)Bm * w;
     const float gam_y = (float)Bm - y2;         // (:161)
     const float gam_x = (float)R - x2;          // (:181)
     float botx = 0.0f, boty = 0.0f;
     for (int c = 0; c < channel; ++c) {
         const float* p = img + (int64_t)c * s1.c;
-        float* gp = gimg + (int64_t)c * s1.c;
+        unsigned long long* gp = gimg + (int64_t)c * h * w;
         const float g = gpx[(int64_t)c * s1.c];
-        atomicAdd(&gp[oT + L], g * (1.0f - alpha) * (1.0f - beta));     // (:151-158)
-        atomicAdd(&gp[oT + R], g * alpha * (1.0f - beta));
-        atomicAdd(&gp[oB + L], g * (1.0f - alpha) * beta);
-        atomicAdd(&gp[oB + R], g * alpha * beta);
+        gradacc_add(&gp[aT + L], g * (1.0f - alpha) * (1.0f - beta), gscale);     // (:151-158)
+        gradacc_add(&gp[aT + R], g * alpha * (1.0f - beta), gscale);
+        gradacc_add(&gp[aB + L], g * (1.0f - alpha) * beta, gscale);
+        gradacc_add(&gp[aB + R], g * alpha * beta, gscale);
         const float tl = p[oT + L], tr = p[oT + R], bl = p[oB + L], br = p[oB + R];
         float temp = gam_y * (tr - tl);
         temp = fmaf(1.0f - gam_y, br - bl, temp);
@@ -140,9 +143,39 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_forward(
     }
 }
 
+// Image gradient of SeparableConv (separableconv_cuda_kernel.cu:122-127 scatters it with atomics: order dependent).
+// Owner computes: image cell (Y, X) receives gout[y, x] * v[fy, y, x] * h[fx, y, x] from the outputs (y, x) =
+// (Y - fy, X - fx); they are summed in the raster order of (y, x) -- the order a sequential run of the reference's
+// loop adds them in -- so the result is deterministic and equals the sequential sum bit for bit.
+__global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_backward_image(
+    const float* __restrict__ in2, const float* __restrict__ in3, const float* __restrict__ gout, float* g1,
+    int channel, int h, int w, int oh, int ow, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so) {
+    const int X = blockIdx.x * VFI_TX + threadIdx.x;
+    const int Y = blockIdx.y * VFI_TY + threadIdx.y;
+    if (X >= w || Y >= h) return;
+    const int b = blockIdx.z;
+    for (int c = 0; c < channel; ++c) {
+        float* cell = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)Y * s1.h + X;
+        float acc = *cell;                                  // caller zero-fills; accumulate as the reference does
+        for (int fy = fs - 1; fy >= 0; --fy) {              // y = Y - fy ascending
+            const int y = Y - fy;
+            if (y < 0 || y >= oh) continue;
+            for (int fx = fs - 1; fx >= 0; --fx) {          // x = X - fx ascending
+                const int x = X - fx;
+                if (x < 0 || x >= ow) continue;
+                const float g = gout[(int64_t)b * so.b + (int64_t)c * so.c + (int64_t)y * so.h + x];
+                const float t2 = in2[(int64_t)b * s2.b + (int64_t)fy * s2.c + (int64_t)y * s2.h + x];
+                const float t3 = in3[(int64_t)b * s3.b + (int64_t)fx * s3.c + (int64_t)y * s3.h + x];
+                acc += g * t2 * t3;
+            }
+        }
+        *cell = acc;
+    }
+}
+
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_backward(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
-    const float* __restrict__ gout, float* g1, float* g2, float* g3, int channel, int oh, int ow, int fs,
+    const float* __restrict__ gout, float* g2, float* g3, int channel, int oh, int ow, int fs,
     vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides so) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
@@ -154,14 +187,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void sepconv_backward(
     float* ghp = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
     for (int c = 0; c < channel; ++c) {
         const float* p = in1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
-        float* gp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
         const float g = gout[(int64_t)b * so.b + (int64_t)c * so.c + (int64_t)y * so.h + x];
         for (int fy = 0; fy < fs; ++fy) {
             const float t2 = vp[(int64_t)fy * s2.c];
             for (int fx = 0; fx < fs; ++fx) {               // (:114-127)
                 const float t3 = hp[(int64_t)fx * s3.c];
                 const float t1 = p[(int64_t)fy * s1.h + fx];
-                atomicAdd(&gp[(int64_t)fy * s1.h + fx], g * t2 * t3);
+                // (the image gradient is gathered by sepconv_backward_image, in the reference's own summation order)
                 // the v / h gradient cells at (y, x) belong to this thread alone
                 gvp[(int64_t)fy * s2.c] += g * t1 * t3;
                 ghp[(int64_t)fx * s3.c] += g * t1 * t2;
@@ -244,9 +276,14 @@ extern "C" int vfi_interpolation_backward(const float* input1, const float* inpu
     if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !gradoutput || !gradinput1 ||
         !gradinput2)
         return VFI_ERR_SHAPE;
+    unsigned long long* acc;
+    int* hdr;
+    const int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    if (err != VFI_OK) return err;
     hipLaunchKernelGGL(interp_backward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, gradoutput, gradinput1, gradinput2, channel, h, w, s1, s2);
-    return launch_status();
+                       input1, input2, gradoutput, acc, hdr, gradinput2, channel, h, w, s1, s2);
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }
 
 extern "C" int vfi_separableconv_forward(const float* input1, const float* input2, const float* input3, float* output,
@@ -270,8 +307,11 @@ extern "C" int vfi_separableconv_backward(const float* input1, const float* inpu
     if (!input1 || !input2 || !input3 || !gradoutput || !gradinput1 || !gradinput2 || !gradinput3)
         return VFI_ERR_SHAPE;
     hipLaunchKernelGGL(sepconv_backward, pixel_grid(ow, oh, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3, channel, oh, ow,
+                       input1, input2, input3, gradoutput, gradinput2, gradinput3, channel, oh, ow,
                        filter_size, s1, s2, s3, so);
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    hipLaunchKernelGGL(sepconv_backward_image, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
+                       input2, input3, gradoutput, gradinput1, channel, h, w, oh, ow, filter_size, s1, s2, s3, so);
     return launch_status();
 }
 

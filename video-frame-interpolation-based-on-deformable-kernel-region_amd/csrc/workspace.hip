@@ -46,6 +46,60 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
     return p;
 }
 
+// ---- deterministic image gradients (vfi_common.h)
+__global__ __launch_bounds__(256) void gradacc_max(const float* __restrict__ g, int channel, int h, int w, vfi_strides sg, int64_t n,
+                                                   int* __restrict__ hdr) {
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int c = (int)((i / ((int64_t)w * h)) % channel);
+        const int b = (int)(i / ((int64_t)w * h * channel));
+        const float v = fabsf(g[(int64_t)b * sg.b + (int64_t)c * sg.c + (int64_t)y * sg.h + x]);
+        m = max(m, v == v ? __float_as_int(v) : 0);        // non-negative floats order like their bits; NaNs do not count
+    }
+    m = wave_max_i32(m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&hdr[0], m);
+}
+
+__global__ __launch_bounds__(256) void gradacc_convert(const unsigned long long* __restrict__ acc, const int* __restrict__ hdr,
+                                                       float* __restrict__ g1, int channel, int h, int w, vfi_strides s1, int64_t n) {
+    int e = 0;
+    (void)frexpf(__int_as_float(hdr[0]), &e);
+    const int k = max(-100, min(100, 36 - e));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long sum = (long long)acc[i];
+        if (sum == 0) continue;
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int c = (int)((i / ((int64_t)w * h)) % channel);
+        const int b = (int)(i / ((int64_t)w * h * channel));
+        float* cell = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
+        *cell += (float)ldexp((double)sum, -k);             // exact integer sum -> float once
+    }
+}
+
+int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
+                  unsigned long long** acc, int** hdr) {
+    const int64_t n = (int64_t)batch * channel * h * w;
+    void* p = ws_get(st, WS_GRADACC, (size_t)n * 8 + 256, false, nullptr);
+    if (!p) return VFI_ERR_LAUNCH;
+    if (hipMemsetAsync(p, 0, (size_t)n * 8 + 256, st) != hipSuccess) return VFI_ERR_LAUNCH;
+    *hdr = static_cast<int*>(p);
+    *acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 256);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gradacc_max, dim3(blocks), dim3(256), 0, st, gout, channel, h, w, sg, n, *hdr);
+    return launch_status();
+}
+
+int gradacc_finish(hipStream_t st, const unsigned long long* acc, const int* hdr, float* g1, int batch, int channel, int h, int w,
+                   vfi_strides s1) {
+    const int64_t n = (int64_t)batch * channel * h * w;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gradacc_convert, dim3(blocks), dim3(256), 0, st, acc, hdr, g1, channel, h, w, s1, n);
+    return launch_status();
+}
+
 int device_cu_count() {
     static int cus[64];                             // 0 = not asked yet; racing first calls write the same value
     int dev = 0;
