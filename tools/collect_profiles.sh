@@ -1,24 +1,31 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for profiles/ on the GPU box:
 #   tools/collect_profiles.sh <tag>      (run from the repo root through gpurun)
-# 1. kernel trace + stats of the default bench command
-# 2. PMC passes (separate runs, --kernel-trace only): FETCH_SIZE, WRITE_SIZE, L2 hit/miss, LDS / wave counters
-#    for the FilterInterpolation C=196 launch, plus a FETCH_SIZE calibration on a launch with known traffic
+# 1. kernel trace + stats of the default bench command (the command the driver runs)
+# 2. PMC passes over the dominant launch (FilterInterpolation, C=196, 1152x1984), separate --pmc runs with --kernel-trace
+#    only: EA read requests / FETCH_SIZE / WRITE_SIZE / L2 hits / LDS and wave counters, for the smooth and the quarter
+#    flow field and two launches of known traffic (invalid = pure copy-through, zero = zero flow)
+# 3. the FETCH_SIZE calibration probe (tools/probes/fetch_size_calibration.hip): every load flavour on known bytes
+# 4. kernel trace of the projection bench (tools/bench_proj.py): the three launches of a call
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/probes/fetch_size_calibration.hip -o /tmp/fetchcal || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
-for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES"; do
-  n=$(echo $ctr | tr " " "_" | cut -c1-24)
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_smooth_$n -- python3 $R/tools/prof_fi.py smooth 196 > /dev/null 2>&1 || exit 1
-done
-for model in invalid zero quarter; do
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${model}_$ctr -- python3 $R/tools/prof_fi.py $model 196 > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
+echo bench-trace-done
+for model in smooth quarter zero invalid; do
+  for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
+    n=$(echo $ctr | cut -d' ' -f1)
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${model}_$n -- python3 $R/tools/prof_fi.py $model 196 > /dev/null 2>&1 || exit 1
   done
+  echo pmc-$model-done
 done
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_smooth_SQ -- python3 $R/tools/prof_fi.py smooth 196 > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_FETCH_SIZE -- /tmp/fetchcal > /dev/null 2>&1 || exit 1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $OUT/cal_RDREQ -- /tmp/fetchcal > /dev/null 2>&1 || exit 1
+echo calibration-done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proj -- python3 $R/tools/bench_proj.py --flows smooth,quarter --iters 50 > $OUT/proj_bench.log 2>&1 || exit 1
 echo collected > $OUT/done

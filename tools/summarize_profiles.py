@@ -10,63 +10,85 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(ROOT, "profiles")
+H, W = 1152, 1984
+PX = H * W
 
 
 def one(pattern):
     # gpurun merges every run's output into gpurun_out/: take the newest file, not the first name
-    hits = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit("missing " + pattern)
     return hits[-1]
 
 
-# 1. kernel stats of the profiled bench run
-shutil.copy(one("bench/*/*kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+def by_shape(trace, out):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"])
+        acc[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "grid_x", "grid_y", "grid_z", "workgroup_x", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for key, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow(list(key) + [len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2),
+                                    round(sum(v) / 1e6, 3)])
+
+
+def counters(d, kernel_substr):
+    f = one(os.path.join(d, "**", "*counter_collection.csv"))
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kernel_substr in r["Kernel_Name"]:
+            vals[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {"%s %s" % k: sum(v) / len(v) for k, v in sorted(vals.items())}
+
+
+# 1. kernel stats + by-shape split of the profiled bench run (the driver's command)
+shutil.copy(one("bench/**/*kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
 with open(os.path.join(src, "bench_under_rocprof.json")) as fh:
     line = [l for l in fh if l.startswith("{")][-1]
 with open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w") as fh:
     fh.write(line)
+by_shape(one("bench/**/*kernel_trace.csv"), os.path.join(dst, tag + "_bench_kernel_by_shape.csv"))
+by_shape(one("proj/**/*kernel_trace.csv"), os.path.join(dst, tag + "_proj_kernel_by_shape.csv"))
 
-# 2. the same trace split by launch geometry (C=196 vs C=3 launches of the same kernel)
-acc = collections.defaultdict(list)
-for r in csv.DictReader(open(one("bench/*/*kernel_trace.csv"))):
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"])
-    acc[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-with open(os.path.join(dst, tag + "_bench_kernel_by_shape.csv"), "w", newline="") as fh:
-    w = csv.writer(fh)
-    w.writerow(["kernel", "grid_x", "grid_y", "grid_z", "workgroup_x", "calls", "avg_us", "min_us", "max_us", "total_ms"])
-    for key, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        w.writerow(list(key) + [len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2),
-                                round(sum(v) / 1e6, 3)])
-
-# 3. PMC means per launch of the C=196 FilterInterpolation kernel
+# 2. PMC means per launch of the C=196 FilterInterpolation kernel
 pmc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    files = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]   # newest run only
-    if not files:
-        continue
-    vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if "fi_forward_ori_lds" in r["Kernel_Name"]:
-            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    pmc[os.path.basename(d)] = {k: sum(v) / len(v) for k, v in sorted(vals.items())}
+    pmc[os.path.basename(d)] = counters(d, "fi_forward_ori_lds")
 with open(os.path.join(dst, tag + "_fi196_pmc.json"), "w") as fh:
     json.dump(pmc, fh, indent=1, sort_keys=True)
 
-# 4. HBM bytes per launch (smooth flow): FETCH_SIZE / WRITE_SIZE are in KB; the window reads (LDS-DMA) count
-#    at ~1, the coalesced flow / filter reads (72 B/px, once per channel group) at 1/2 -- profiles/README.md
-px = 1152 * 1984
-groups = 2
-fetch = pmc["pmc_smooth_FETCH_SIZE"]["FETCH_SIZE"] * 1024.0
-write = pmc["pmc_smooth_WRITE_SIZE"]["WRITE_SIZE"] * 1024.0
-half_counted = 72.0 * px * groups / 2.0
-traffic = {"hbm_bytes_per_launch": fetch + half_counted + write, "fetch_bytes_counted": fetch,
-           "flow_filter_bytes_half_counted_correction": half_counted, "write_bytes": write,
-           "algorithmic_bytes": 1640.0 * px, "source": tag + "_fi196_pmc.json"}
-with open(os.path.join(dst, "fi196_traffic.json"), "w") as fh:
-    json.dump(traffic, fh, indent=1)
-print(json.dumps(traffic))
+# 3. the calibration: every load flavour reads the same 1.79 GB exactly once
+true_bytes = 196 * PX * 4
+cal = {"true_bytes_per_launch": true_bytes, "kernels": {}}
+cf, cr = counters(os.path.join(src, "cal_FETCH_SIZE"), "calib_"), counters(os.path.join(src, "cal_RDREQ"), "calib_")
+for k, v in cf.items():
+    name = k.split(" ")[0]
+    rd = cr.get(name + " TCC_EA0_RDREQ_sum", 0.0)
+    cal["kernels"][name] = {"FETCH_SIZE_bytes_over_true": round(v * 1024.0 / true_bytes, 4), "EA_RDREQ": rd,
+                            "EA_RDREQ_32B": cr.get(name + " TCC_EA0_RDREQ_32B_sum", 0.0),
+                            "RDREQ_x_128B_over_true": round(rd * 128.0 / true_bytes, 4)}
+with open(os.path.join(dst, tag + "_fetch_calibration.json"), "w") as fh:
+    json.dump(cal, fh, indent=1, sort_keys=True)
+
+# 4. HBM-side bytes per launch: reads = EA read requests x 128 B (the calibration: every flavour, the LDS-DMA window
+#    loads included, issues 128-byte requests that FETCH_SIZE tallies at 64), writes = WRITE_SIZE (KB, exact)
+entries = []
+for model in ("smooth", "quarter"):
+    kn = [k for k in pmc["pmc_%s_TCC_EA0_RDREQ_sum" % model] if k.endswith("TCC_EA0_RDREQ_sum")][0]
+    rd = pmc["pmc_%s_TCC_EA0_RDREQ_sum" % model][kn] * 128.0
+    wk = [k for k in pmc["pmc_%s_WRITE_SIZE" % model] if k.endswith("WRITE_SIZE")][0]
+    wr = pmc["pmc_%s_WRITE_SIZE" % model][wk] * 1024.0
+    entries.append({"h": H, "w": W, "flow_model": model, "direct": False, "kernel": kn.split(" ")[0],
+                    "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+                    "algorithmic_bytes": 1640.0 * PX, "ratio": round((rd + wr) / (1640.0 * PX), 3),
+                    "source": "profiles/%s_fi196_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
+with open(os.path.join(dst, "traffic_by_config.json"), "w") as fh:
+    json.dump({"entries": entries}, fh, indent=1)
+print(json.dumps(entries, indent=1))
