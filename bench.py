@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no gate / quarter / fp16 measurements)")
     ap.add_argument("--direct", action="store_true", help="force the direct-gather FilterInterpolation kernel")
+    ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
     return ap.parse_args(argv)
@@ -174,9 +175,29 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
                 assert cabi.flowprojection_forward(p.flows[d], p.count, p.proj, 1) == 0
                 assert cabi.filterinterp_forward_ori(p.frames[d], p.proj, p.filters[d], p.out[d]) == 0
 
-    for i in range(args.warmup):
+    for i in range(max(1, args.warmup)):
         step(i)
-    elapsed = runner.timed_region(step, args.steps, dev)
+    # 896 short launches per step (14 per pair): the host's ctypes calls, not the GPU, would set the pace.  The step is
+    # captured once into a HIP graph (every entry point is capturable: no host synchronisation, workspaces already sized
+    # by the warm-up) and replayed; --no-graph times the eager calls.
+    launch, run = "eager calls", step
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step(0)                                     # warm-up on the capture stream: its workspaces
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    step(0)
+            torch.cuda.synchronize(dev)
+            launch, run = "one HIP graph per step (captured once, replayed)", lambda _i: graph.replay()
+            run(0)
+        except Exception as exc:                            # capture unsupported: say so and time the eager calls
+            launch = "eager calls (graph capture failed: %s)" % type(exc).__name__
+            run = step
+    elapsed = runner.timed_region(run, args.steps, dev)
     frames_total = runner.total_units(len(mine) * args.steps)
     h, w = pairs[0].h, pairs[0].w
     return {
@@ -189,7 +210,7 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
                                "2 FlowProjection(fillhole) + 2 FilterInterpolation(C=3)), B=1 per call; 1 frame per pair"
                                % (h, w),
                    "pairs": n_pairs, "pairs_per_rank": [len(runner.shard_pairs(n_pairs, r, world)) for r in range(world)],
-                   "filter_size": 4, "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
+                   "filter_size": 4, "launch": launch, "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
     }
 
 

@@ -394,6 +394,118 @@ __global__ __launch_bounds__(256) void corr_forward_generic(
     out[gid] = acc / (float)(k * k * channel);
 }
 
+// The at::Half instantiation for PWC-Net's configuration, tiled like corr_forward_k1_rows2: 32x4 output pixels per
+// workgroup, one wave per displacement row, a lane owns two adjacent pixels.  Both maps are staged as halves
+// (8-byte units); per channel and displacement ONE packed multiply forms the two pixels' products, each rounded to
+// half exactly as the reference's `rInput1[i] * rInput2[i]` on two Half values (correlation_cuda_kernel.cu:124), and
+// two mixed-precision adds accumulate them in float, channels in sequence.  Same bits as corr_forward_generic_f16.
+template <int MD>
+__global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2_f16(
+    const __half* __restrict__ in1, const __half* __restrict__ in2, __half* __restrict__ out,
+    int channel, int h, int w, int oh, int ow, int org) {
+    constexpr int D = 2 * MD + 1;
+    constexpr int TW = 32, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;          // LW = 40 halves: 10 aligned 8-byte units
+    constexpr int NT = 64 * D;
+    constexpr int UW = LW / 4, NU = CORR_CC_ROWS * LH * UW;
+    constexpr int NPT = (NU + NT - 1) / NT;
+    constexpr int FU = CORR_CC_ROWS * TH * (TW / 4);
+    constexpr int NF1 = (FU + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) __half tile[CORR_CC_ROWS][LH][LW];
+    __shared__ __attribute__((aligned(16))) __half f1s[CORR_CC_ROWS][TH * TW];
+
+    const int lane = threadIdx.x, tj = threadIdx.y;
+    const int tid = tj * 64 + lane;
+    const int px = 2 * (lane & 15), py = lane >> 4;
+    const int ox = blockIdx.x * TW + px, oy = blockIdx.y * TH + py;
+    const int b = blockIdx.z;
+    const int64_t plane = (int64_t)h * w;
+    const __half* f1 = in1 + (int64_t)b * channel * plane;
+    const __half* f2 = in2 + (int64_t)b * channel * plane;
+    const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;
+
+    int soff[NPT], sch[NPT];
+    bool sok[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (LH * UW), rem = e - c * (LH * UW);
+        const int r = rem / UW, col = 4 * (rem - r * UW);
+        const int gy = wy0 + r, gx = wx0 + col;
+        sch[k] = c;
+        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = sok[k] ? gy * w + gx : 0;
+    }
+    int foff[NF1], fch[NF1];
+    bool fok[NF1];
+#pragma unroll
+    for (int k = 0; k < NF1; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
+        const int gy = blockIdx.y * TH + rem / (TW / 4) + org, gx = blockIdx.x * TW + 4 * (rem % (TW / 4)) + org;
+        fch[k] = c;
+        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = fok[k] ? gy * w + gx : 0;
+    }
+
+    float acc[2][D];
+#pragma unroll
+    for (int ti = 0; ti < D; ++ti) { acc[0][ti] = 0.0f; acc[1][ti] = 0.0f; }
+
+    uint2 nv[NPT], nf[NF1];
+    const uint2 zero = make_uint2(0u, 0u);
+    auto fetch = [&](int c0) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const uint2*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+#pragma unroll
+        for (int k = 0; k < NF1; ++k)
+            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const uint2*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < channel; c0 += CORR_CC_ROWS) {
+        const int cn = min(CORR_CC_ROWS, channel - c0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < NU) reinterpret_cast<uint2*>(&tile[0][0][0])[e] = nv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int e = tid + k * NT;
+            if (e < FU) reinterpret_cast<uint2*>(&f1s[0][0])[e] = nf[k];
+        }
+        __syncthreads();
+        if (c0 + CORR_CC_ROWS < channel) fetch(c0 + CORR_CC_ROWS);
+        for (int c = 0; c < cn; ++c) {
+            const __half2 a = *reinterpret_cast<const __half2*>(&f1s[c][py * TW + px]);
+            const __half2* row = reinterpret_cast<const __half2*>(&tile[c][py + tj][px]);
+            __half2 r[(D + 1) / 2];
+#pragma unroll
+            for (int k = 0; k < (D + 1) / 2; ++k) r[k] = row[k];
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti) {
+                // (t[ti], t[ti + 1]): pixel 0 meets displacement column ti, pixel 1 the next one
+                const __half2 pair = (ti & 1) ? __halves2half2(__high2half(r[ti / 2]), __low2half(r[ti / 2 + 1])) : r[ti / 2];
+                const __half2 p = __hmul2(a, pair);                        // two products, each rounded to half
+                // acc + (float)product in one mixed-precision instruction (fma(p, 1, acc): one rounding, the float add's)
+                const unsigned pb = __builtin_bit_cast(unsigned, p);
+                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[0][ti]) : "v"(pb));
+                asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[1][ti]) : "v"(pb));
+            }
+        }
+    }
+    const float nelems = (float)channel;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (ox + q < ow && oy < oh) {
+            __half* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = __float2half_rn(acc[q][ti] / nelems);
+        }
+}
+
 // half inputs and output, the reference's `scalar_t = at::Half` instantiation (correlation_cuda_kernel.cu:386,403):
 // each product is formed in half (`rInput1[i] * rInput2[i]` on two Half values: one rounding to half, :124),
 // widened and accumulated in float; the mean is rounded to half once (:143).  One thread per output element,
@@ -576,6 +688,18 @@ extern "C" int vfi_correlation_forward_f16(const void* input1, const void* input
     const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
     const int64_t total = (int64_t)batch * oc * oh * ow;
     if ((total + 255) / 256 > INT_MAX) return VFI_ERR_SHAPE;
+    if (kernel_size == 1 && stride1 == 1 && stride2 == 1 && max_displacement == 4) {
+        // PWC-Net's configuration on frames whose rows are 8-byte aligned, enough tiles to fill the chip: the tiled kernel
+        const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
+        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
+                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 7) == 0;
+        if (aligned && small_tiles >= g_corr_flat_threshold) {
+            const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
+            hipLaunchKernelGGL(corr_forward_k1_rows2_f16<4>, grid, dim3(64, 9, 1), 0, (hipStream_t)stream, (const __half*)input1,
+                               (const __half*)input2, (__half*)output, channel, h, w, oh, ow, max_displacement - pad_size);
+            return launch_status();
+        }
+    }
     hipLaunchKernelGGL(corr_forward_generic_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __half*)input1, (const __half*)input2, (__half*)output, batch, channel, h, w, oc, oh, ow,
                        pad_size, kr, max_displacement, stride1, stride2, dr);
