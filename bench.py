@@ -65,6 +65,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no gate / quarter / fp16 measurements)")
     ap.add_argument("--direct", action="store_true", help="force the direct-gather FilterInterpolation kernel")
+    ap.add_argument("--storage", choices=("f32", "f16"), default="f32",
+                    help="slowmo1080: f16 = BASELINE.json configs[2], frames / context / correlation features and their "
+                         "outputs stored as fp16, flows, filters, depth and all arithmetic fp32")
     ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
@@ -92,6 +95,15 @@ class SlowmoPair:
         self.count, self.proj = e(1, 1, h, w), e(1, 2, h, w)
         self.out_ctx, self.out_img = e(1, 196, h, w), e(1, 3, h, w)
         self.gen = gen
+
+    def to_half_storage(self, torch):
+        """configs[2]: what the network stores as activations becomes fp16; flows, filters and depth stay fp32"""
+        self.frames = [t.half() for t in self.frames]
+        self.ctx = [t.half() for t in self.ctx]
+        self.corr = [[(a.half(), b.half()) for a, b in lv] for lv in self.corr]
+        self.out_ctx, self.out_img = self.out_ctx.half(), self.out_img.half()
+        torch.cuda.empty_cache()
+        return self
 
 
 class VimeoPair:
@@ -219,9 +231,13 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     wl = SlowmoPair(torch, S, dev, h, w, args.flow_model, S.SEED + rank)
     px = wl.px
     fi196_events = []
+    half = args.storage == "f16"
+    if half:
+        wl.to_half_storage(torch)
+    fi_call = cabi.filterinterp_forward_ori_f16 if half else cabi.filterinterp_forward_ori
 
     def fi(img, flow, filt, out):
-        err = cabi.filterinterp_forward_ori(img, flow, filt, out, direct=args.direct)
+        err = fi_call(img, flow, filt, out, direct=args.direct)
         assert err == 0, err
 
     def step(i, record=False):
@@ -252,35 +268,40 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     fi196_ms = sum(a.elapsed_time(b) for a, b in fi196_events) / max(1, len(fi196_events))
     kernel = ("fi_forward_ori_lds (FilterInterpolation _ori forward, C=196, fs=4)" if not args.direct
               else "fi_forward_ori_direct<true> (C=196)")
-    roofline = roofline_block(kernel, px, fi196_ms, len(fi196_events), traffic_lookup(h, w, args.flow_model, args.direct))
+    if half:
+        kernel = kernel.replace("fi_forward_ori_lds", "fi_forward_ori_lds_f16").replace("direct<true>", "direct_f16")
+    roofline = roofline_block(kernel, px, fi196_ms, len(fi196_events),
+                              None if half else traffic_lookup(h, w, args.flow_model, args.direct), 856.0 if half else 1640.0)
 
     out = {
         "metric": "interpolated frames/sec at 1080p (hot path only: correlation + DepthFlowProjection + "
                   "FilterInterpolation of DAIN_slowmotion x4)",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 arithmetic, f16 storage" if half else "f32", "data": "synthetic",
         "config": {"workload": "DAIN_slowmotion x4 hot path, one %dx%d pair padded to %dx%d per step per GPU: "
                                "10 correlation(pad4,k1,md4) + 6 DepthFlowProjection(fillhole) + "
                                "6 FilterInterpolation(C=196) + 6 FilterInterpolation(C=3); 3 frames/step"
                                % (args.height, args.width, h, w),
-                   "flow_model": args.flow_model, "filter_size": 4, "batch": 1,
+                   "flow_model": args.flow_model, "filter_size": 4, "batch": 1, "storage": args.storage,
                    "parallelism": "replicas x%d (one pair per GPU, no collective)" % world},
         "roofline": roofline,
     }
+    if half:
+        return out              # the side measurements and the CPU baseline belong to the fp32 headline
     if rank == 0 and not args.no_extras:
         if args.flow_model != "quarter":
             out["roofline_quarter"] = quarter_measurement(torch, cabi, S, wl, dev, args, kernel)
         out["gate"] = gate_measurement(torch, cabi, S, wl, dev, args)
-        out["fp16_storage"] = fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step)
+        out["fp16_storage"] = fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank)
         out["shared_window"] = shared_window_measurement(torch, cabi, wl, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cabi, wl, dev, args)
     return out
 
 
-def roofline_block(kernel, px, ms, launches, traffic):
-    nbytes = 1640.0 * px
+def roofline_block(kernel, px, ms, launches, traffic, bytes_per_px=1640.0):
+    nbytes = bytes_per_px * px
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": nbytes,
@@ -352,22 +373,43 @@ def gate_measurement(torch, cabi, S, wl, dev, args, iters=60):
     return res
 
 
-def fp16_storage_measurement(torch, cabi, wl, dev, fi196_ms, ms_per_step, iters=12):
-    """BASELINE.json configs[2] names "fp16 storage / fp32 accum": the dominant launch with the context
-    tensor and its output stored as fp16 (856 B/px algorithmic).  Reported beside the fp32
-    headline, never as `value`."""
-    ctx16 = [c.to(torch.float16) for c in wl.ctx]
-    out16 = torch.empty_like(ctx16[0])
-    flow, filt = wl.flows[0][1], wl.filters[0]
+def fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank):
+    """BASELINE.json configs[2] ("fp16 storage / fp32 accum"): the SAME step with frames, context, correlation features
+    and their outputs stored as fp16 -- `bench.py --storage f16` runs it as the timed region; here a short measured
+    run of it is reported beside the fp32 headline, never as `value`.  Step time and launch time are measured."""
+    wl = SlowmoPair(torch, S, dev, h, w, args.flow_model, S.SEED + rank).to_half_storage(torch)
+    events = []
 
-    def run(i):
-        assert cabi.filterinterp_forward_ori_f16(ctx16[i % 2], flow, filt, out16) == 0
-    ms = hip_timed(torch, dev, run, iters, nsets=2)
+    def step(i, record=False):
+        for d in range(2):
+            for a, b in wl.corr[d]:
+                cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+            for ti in range(len(TIMES)):
+                assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, wl.proj, 1) == 0
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                assert cabi.filterinterp_forward_ori_f16(wl.ctx[d], wl.proj, wl.filters[d], wl.out_ctx, direct=args.direct) == 0
+                if record:
+                    e1.record()
+                    events.append((e0, e1))
+                assert cabi.filterinterp_forward_ori_f16(wl.frames[d], wl.proj, wl.filters[d], wl.out_img, direct=args.direct) == 0
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize(dev)
+    steps = max(5, args.steps // 2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, record=True)
+    torch.cuda.synchronize(dev)
+    step_ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     gbs = 856.0 * wl.px / ms / 1e6
-    step_ms = ms_per_step - 6.0 * (fi196_ms - ms)
     return {"kernel": "fi_forward_ori_lds_f16 (C=196, image and output fp16, flow / filter / arithmetic fp32)",
             "avg_launch_ms": round(ms, 4), "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
-            "frames_per_s_if_the_6_context_launches_used_it": round(3.0 / (step_ms * 1e-3), 1)}
+            "steps_timed": steps, "ms_per_step": round(step_ms, 4), "frames_per_s": round(len(TIMES) / (step_ms * 1e-3), 1),
+            "step": "measured: 10 half correlations + 6 DepthFlowProjection (fp32) + 6 + 6 half-storage FilterInterpolation"}
 
 
 def shared_window_measurement(torch, cabi, wl, dev, args):

@@ -764,6 +764,46 @@ def test_correlation_half(torch_mod, cabi, oracle):
         correlation_cuda.forward(a, b.float(), a.new_empty(0), a.new_empty(0), a.new_empty(0), 4, 1, 4, 1, 1, 1)
 
 
+def test_correlation_half_tiled_kernel(torch_mod, cabi, oracle):
+    """PWC-Net's configuration on 8-byte aligned rows takes the tiled half kernel (corr_forward_k1_rows2_f16: packed half
+    products, mixed-precision float adds): bit-exact with the half restatement, including half subnormals, products
+    that overflow to inf, ragged right / bottom tiles and a channel count that is not a multiple of the LDS chunk."""
+    torch = torch_mod
+    rng = np.random.default_rng(41)
+    for (B, C, H, W) in ((1, 16, 64, 64), (2, 19, 36, 68), (1, 5, 70, 132)):     # 256, 306, 342 16x4 tiles: the tiled kernel
+        f1 = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        f2 = rng.standard_normal((B, C, H, W)).astype(np.float16)
+        f1[:, 0, ::3, ::5] = np.float16(6.0e-8)              # smallest subnormals
+        f2[:, 0, 1::3, ::7] = np.float16(3.0e-6)
+        f1[:, 1, ::9, 1::4] = np.float16(300.0)              # 300 * 300 > 65504: the rounded product is inf
+        f2[:, 1, ::9, 1::4] = np.float16(300.0)
+        f2[:, 2, 5::11, 2::6] = np.float16(-0.0)
+        want = oracle.correlation_fwd_f16(f1, f2, 4, 1, 4, 1, 1)
+        got = cabi.correlation_forward(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), 4, 1, 4, 1, 1)
+        assert got.dtype == torch.float16
+        g = got.cpu().numpy()
+        assert np.array_equal(g.view(np.uint16), want.view(np.uint16)), (B, C, H, W)
+        assert np.isinf(g).any()
+
+
+def test_correlation_half_1080p_tiled_equals_one_thread_per_output(torch_mod, cabi):
+    """At the PWC pyramid's 1080p level sizes the tiled half kernel and the one-thread-per-output half kernel (taken when
+    the maps are not 8-byte aligned: here a view that starts one half into its buffer) return the same bits."""
+    torch = torch_mod
+    gen = torch.Generator(device="cpu").manual_seed(43)
+    for (C, H, W) in ((32, 272, 480), (64, 136, 240), (96, 68, 120)):
+        f1 = torch.randn(1, C, H, W, generator=gen).half().cuda()
+        f2 = torch.randn(1, C, H, W, generator=gen).half().cuda()
+        tiled = cabi.correlation_forward(f1, f2, 4, 1, 4, 1, 1)
+        n = f1.numel()
+        b1, b2 = torch.empty(n + 1, dtype=torch.float16, device="cuda"), torch.empty(n + 1, dtype=torch.float16, device="cuda")
+        u1, u2 = b1[1:].view(1, C, H, W), b2[1:].view(1, C, H, W)
+        u1.copy_(f1), u2.copy_(f2)
+        assert u1.data_ptr() % 8 != 0
+        plain = cabi.correlation_forward(u1, u2, 4, 1, 4, 1, 1)
+        assert torch.equal(tiled.view(torch.int16), plain.view(torch.int16))
+
+
 def test_frame_ssim(torch_mod, cabi, oracle):
     """SSIM as demo_MiddleBury.py:382-388 reports it; float32 on the GPU against the float64 oracle."""
     torch = torch_mod

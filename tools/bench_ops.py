@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-op timing on the GPU (HIP events on the launch stream), for kernel development.
 
-    python tools/bench_ops.py [--ops fi196,fi3,proj,dproj,corr] [--flows smooth,quarter] [--iters 20]
+    python tools/bench_ops.py [--ops fi196,fi3,proj,dproj,corr,corr16] [--flows smooth,quarter] [--iters 20]
 Prints one line per (op, flow): mean ms and algorithmic GB/s (SURVEY.md 8d byte counts).
 """
 import argparse
@@ -201,6 +201,23 @@ def main():
             tot_b += nb
             print("corr  C=%-3d %4dx%-4d   %8.4f ms %8.1f GB/s" % (a.shape[1], a.shape[2], a.shape[3], ms, nb / ms / 1e6), flush=True)
         print("corr  5 levels         %8.4f ms %8.1f GB/s" % (tot_ms, tot_b / tot_ms / 1e6))
+    if "corr16" in ops:
+        # half storage: the tiled kernel against the one-thread-per-output kernel (taken for maps that are not 8-byte aligned)
+        tot, tot_plain = 0.0, 0.0
+        for a, b in S.correlation_features(1, h, w, gen):
+            a, b = a.to(dev).half(), b.to(dev).half()
+            ms = timed(lambda: cabi.correlation_forward(a, b, 4, 1, 4, 1, 1), args.iters * 2)
+            n = a.numel()
+            u1 = torch.empty(n + 1, dtype=torch.float16, device=dev)[1:].view(a.shape)
+            u2 = torch.empty(n + 1, dtype=torch.float16, device=dev)[1:].view(a.shape)
+            u1.copy_(a), u2.copy_(b)
+            ms_plain = timed(lambda: cabi.correlation_forward(u1, u2, 4, 1, 4, 1, 1), args.iters * 2)
+            nb = (2 * a.shape[1] + 81) * 2.0 * a.shape[2] * a.shape[3]
+            tot += ms
+            tot_plain += ms_plain
+            print("corr16 C=%-3d %4dx%-4d   %8.4f ms %8.1f GB/s | one thread per output %8.4f ms"
+                  % (a.shape[1], a.shape[2], a.shape[3], ms, nb / ms / 1e6, ms_plain), flush=True)
+        print("corr16 5 levels         %8.4f ms | one thread per output %8.4f ms" % (tot, tot_plain))
 
 
 if __name__ == "__main__":

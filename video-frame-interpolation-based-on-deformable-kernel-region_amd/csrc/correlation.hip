@@ -693,7 +693,8 @@ extern "C" int vfi_correlation_forward_f16(const void* input1, const void* input
         const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
         const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
                              ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 7) == 0;
-        if (aligned && small_tiles >= g_corr_flat_threshold) {
+        // (measured at the 1080p pyramid: 144 such tiles 27 us tiled vs 21 us one thread per output; 576 tiles 33 vs 101)
+        if (aligned && small_tiles >= 4 * g_corr_flat_threshold) {
             const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
             hipLaunchKernelGGL(corr_forward_k1_rows2_f16<4>, grid, dim3(64, 9, 1), 0, (hipStream_t)stream, (const __half*)input1,
                                (const __half*)input2, (__half*)output, channel, h, w, oh, ow, max_displacement - pad_size);
