@@ -770,7 +770,7 @@ def test_correlation_half_tiled_kernel(torch_mod, cabi, oracle):
     that overflow to inf, ragged right / bottom tiles and a channel count that is not a multiple of the LDS chunk."""
     torch = torch_mod
     rng = np.random.default_rng(41)
-    for (B, C, H, W) in ((1, 16, 64, 64), (2, 19, 36, 68), (1, 5, 70, 132)):     # 256, 306, 342 16x4 tiles: the tiled kernel
+    for (B, C, H, W) in ((1, 16, 64, 256), (2, 19, 68, 132), (1, 5, 70, 260)):   # 256, 306, 306 16x4 tiles: the tiled kernel
         f1 = rng.standard_normal((B, C, H, W)).astype(np.float16)
         f2 = rng.standard_normal((B, C, H, W)).astype(np.float16)
         f1[:, 0, ::3, ::5] = np.float16(6.0e-8)              # smallest subnormals
