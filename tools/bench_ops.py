@@ -201,6 +201,36 @@ def main():
             tot_b += nb
             print("corr  C=%-3d %4dx%-4d   %8.4f ms %8.1f GB/s" % (a.shape[1], a.shape[2], a.shape[3], ms, nb / ms / 1e6), flush=True)
         print("corr  5 levels         %8.4f ms %8.1f GB/s" % (tot_ms, tot_b / tot_ms / 1e6))
+    if "fitypes" in ops:
+        # the C=196 launch against what its windows have to fetch: no windows at all (every pixel invalid: copy-through),
+        # the smallest window (zero flow), constant flows with different alignments, smooth fields of growing magnitude
+        def const(fx, fy):
+            f = torch.empty((1, 2, h, w), device=dev)
+            f[:, 0], f[:, 1] = fx, fy
+            return f
+        cases = [("invalid (copy-through)", const(1.0e6, 1.0e6)), ("zero", const(0.0, 0.0)), ("const +5.5,+3.25", const(5.5, 3.25)),
+                 ("const +32.5,+0.25", const(32.5, 0.25)), ("const +0.5,+16.25", const(0.5, 16.25))]
+        for sg in (2.0, 8.0):
+            cases.append(("smooth sigma %g" % sg, S.flow(1, h, w, sg * w / 1984.0, gen, "smooth").to(dev)))
+        # separate "bigger window" from "lanes read different windows": one outlier pixel per tile widens the bounding box
+        # while every other lane still reads consecutive addresses; 0/1-pixel jitter keeps the box small but scatters lanes
+        f = const(0.0, 0.0)
+        f[:, 0, 0::16, 0::64], f[:, 1, 0::16, 0::64] = 9.0, 5.0
+        cases.append(("zero + outlier(+9,+5)/tile", f))
+        f = const(0.0, 0.0)
+        f[:, 0, 0::16, 0::64], f[:, 1, 0::16, 0::64] = 18.0, 10.0
+        cases.append(("zero + outlier(+18,+10)/tile", f))
+        g = torch.Generator(device="cpu").manual_seed(5)
+        jx = torch.randint(0, 2, (1, 1, h, w), generator=g).float().to(dev)
+        jy = torch.randint(0, 2, (1, 1, h, w), generator=g).float().to(dev)
+        cases.append(("jitter x in {0,1}", torch.cat([jx, jx * 0], 1).contiguous()))
+        cases.append(("jitter y in {0,1}", torch.cat([jy * 0, jy], 1).contiguous()))
+        cases.append(("jitter x,y in {0,1}", torch.cat([jx, jy], 1).contiguous()))
+        j4 = torch.randint(0, 8, (1, 2, h, w), generator=g).float().to(dev)
+        cases.append(("jitter x,y in {0..7}", j4))
+        for name, f in cases:
+            ms = timed(lambda: cabi.filterinterp_forward_ori(ctx, f, filt, out196), args.iters)
+            print("fitypes %-24s %8.4f ms %8.1f GB/s" % (name, ms, 1640.0 * px / ms / 1e6), flush=True)
     if "corr16" in ops:
         # half storage: the tiled kernel against the one-thread-per-output kernel (taken for maps that are not 8-byte aligned)
         tot, tot_plain = 0.0, 0.0

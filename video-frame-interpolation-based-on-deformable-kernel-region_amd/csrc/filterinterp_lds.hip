@@ -59,6 +59,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
 #define FI_KTOP 15                                  // staged elements per thread and channel, at most
 #define FI_XCDS 8
+#ifdef VFI_DEV
+#define FI_ABL(flags) (((flags) >> 20) & 63)        // development: parts of the lean loop switched off (wrong results, timing only)
+#else
+#define FI_ABL(flags) 0
+#endif
 
 typedef __attribute__((address_space(3))) void* fi_lptr_t;
 
@@ -69,7 +74,8 @@ struct FiWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
 struct FiPixel {
     bool valid, inimg;
     float alpha, beta;
-    int lbase;              // LDS index of the pixel's 4x4 window origin inside a staged window
+    int lbase;              // LDS index of the pixel's 4x4 window origin inside a staged window (B64: rounded down to even)
+    bool odd;               // B64: the origin's column inside the window is odd
     unsigned pix;           // element offset of the pixel inside an image plane
     float f[16];
 };
@@ -124,32 +130,40 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
     const int D = R - 1;                                    // windows in flight
     auto issue = [&](int c, int slot) {
         const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
+        // (the LDS destination is M0 = the wave's first element.  Formed on the scalar unit from a provably uniform wave id it
+        //  would save a vector add and a v_readfirstlane per load -- but hipcc then sees the DMA target alias the tap reads
+        //  and drains vmcnt before every LDS read: 1.05 -> 1.61 ms.  From tid it does not.)
         float* l = ring + slot * NP + tid;
 #pragma unroll
         for (int k = 0; k < K; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS), 4, goff[k], 0, 0, 0);
     };
+    auto finish = [&](int c, int p, const float (&v)[16], float* o) {
+        const float val = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+        o[px[p].pix] = val;
+        if constexpr (BLEND) {
+            // (a load inside the counted-vmcnt loop drains the ring -- harmless here: a frame's three windows
+            //  were all issued before the loop)
+            const float* bi = bl.other + (int64_t)c * cs;
+            const float q0 = bi[px[p].pix] * bl.w0, q2 = val * bl.w2;
+            float* bo = bl.out + (int64_t)c * cs;               // (wave-uniform plane pointer + 32-bit pixel offset)
+            bo[px[p].pix] = q0 + q2;
+        }
+    };
     auto compute = [&](int c, int slot) {
         float* o = out + (int64_t)c * cs;
         const float* base = ring + slot * NP;
+        {
 #pragma unroll
-        for (int p = 0; p < FI_PX; ++p) {
-            if (px[p].valid) {
-                const float* t = base + px[p].lbase;
-                float v[16];
+            for (int p = 0; p < FI_PX; ++p) {
+                if (px[p].valid) {
+                    const float* t = base + px[p].lbase;
+                    float v[16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.pitch + k];
-                const float val = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
-                o[px[p].pix] = val;
-                if constexpr (BLEND) {
-                    // (a load inside the counted-vmcnt loop drains the ring -- harmless here: a frame's three windows
-                    //  were all issued before the loop)
-                    const float* bi = bl.other + (int64_t)c * cs;
-                    const float q0 = bi[px[p].pix] * bl.w0, q2 = val * bl.w2;
-                    float* bo = bl.out + (int64_t)c * cs;               // (wave-uniform plane pointer + 32-bit pixel offset)
-                    bo[px[p].pix] = q0 + q2;
+                        for (int k = 0; k < 4; ++k) v[r * 4 + k] = t[r * win.pitch + k];
+                    finish(c, p, v, o);
                 }
             }
         }
@@ -187,8 +201,182 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
             }
 }
 
+// The same channel loop written for the fewest instructions per pixel.  Counters and ablations say what bounds the
+// plain loop is instruction issue, not bytes: a launch with neither window staging nor result stores still takes 0.88 of
+// 1.05 ms, SQ_ACTIVE_INST_ANY x 4 waves fills a SIMD's cycles, 38 % fewer LDS cycles (8-byte reads) or overlapping
+// the LDS reads with the arithmetic change nothing, and a wave of the plain loop issues ~175 instructions per channel for
+// 2 x (8 tap reads + 21 multiply-adds + 1 store).  Here:
+//  * the ring geometry is a compile-time function of K: the steady-state wait is ONE s_waitcnt with a constant
+//    (the plain loop recomputes min(c + D, last) - (c + 1) and branches four ways every channel); the last D channels run
+//    in a second loop that waits for everything;
+//  * plane descriptors advance by one plane per channel (two scalar adds) instead of a 64-bit multiply;
+//  * the DMA destination M0 comes from a wave id the compiler can see is uniform: one scalar add per load instead of a
+//    vector add + v_readfirstlane + s_mov (safe only because the tap reads are asm: see issue() in the plain loop);
+//  * tap reads are asm with two hand-placed lgkmcnt waits per channel instead of fourteen, and the second pixel's first
+//    reads are in flight while the first pixel is multiplied;
+//  * results leave through buffer stores whose offset is out of range for an invalid pixel: no exec-mask juggling.
+template <int K, bool B64>
+__device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
+                                                     int c_begin, int c_end, int tid, const FiWindow& win,
+                                                     const FiPixel (&px)[FI_PX], float* __restrict__ ring, int abl) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    static_assert(FI_PX == 2, "two pixels per thread");
+    constexpr int NP = K * FI_THREADS;
+    constexpr int R = (FI_RING_FLOATS / NP) < FI_RMAX ? (FI_RING_FLOATS / NP) : FI_RMAX;
+    constexpr int D = R - 1;
+    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    if (c_begin >= c_end) return;
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + k * FI_THREADS;
+        const int r = e / win.pitch;
+        const int col = e - r * win.pitch;
+        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+        goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
+    }
+    const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(fi_lptr_t)ring;
+    const unsigned pitch4 = 4u * (unsigned)win.pitch;
+    unsigned lb[FI_PX], soff[FI_PX];
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p) {
+        lb[p] = ring_lds + 4u * (unsigned)px[p].lbase;          // (an invalid pixel's reads land past the LDS: they return 0)
+        soff[p] = px[p].valid ? 4u * px[p].pix : 0x80000000u;   // (and its store is dropped by the range check)
+    }
+    // filter taps as (left quadrant, right quadrant) pairs: rows 0-1 feed the top sums, rows 2-3 the bottom ones
+    v2f F[FI_PX][8];
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            F[p][2 * r] = v2f{px[p].f[4 * r], px[p].f[4 * r + 2]};
+            F[p][2 * r + 1] = v2f{px[p].f[4 * r + 1], px[p].f[4 * r + 3]};
+        }
+    const int last = c_end - 1;
+    const float* pdma = img + (int64_t)c_begin * cs;            // plane the next window is staged from
+    float* pout = out + (int64_t)c_begin * cs;                  // plane the next results go to
+    auto issue = [&](int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
+        float* l = ring + slot * NP + wave_first;
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS), 4, goff[k], 0, 0, 0);
+        }
+        pdma += cs;
+    };
+#define FI_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
+#define FI_READ64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
+    auto compute = [&](int slot) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, plane_bytes, 0x00020000);
+        unsigned a0[4], a1[4];
+        a0[0] = lb[0] + so; a1[0] = lb[1] + so;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) { a0[r] = a0[r - 1] + pitch4; a1[r] = a1[r - 1] + pitch4; }
+        if constexpr (B64) {
+            // aligned 8-byte reads, three per tap row (see the plain loop): at most 15 LDS reads outstanding
+            v2f q0[12], q1[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { FI_READ64(q0[3 * r], a0[r], 0); FI_READ64(q0[3 * r + 1], a0[r], 8); FI_READ64(q0[3 * r + 2], a0[r], 16); }
+            FI_READ64(q1[0], a1[0], 0); FI_READ64(q1[1], a1[0], 8); FI_READ64(q1[2], a1[0], 16);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q0[4]), "+v"(q0[5]),
+                                                   "+v"(q0[6]), "+v"(q0[7]), "+v"(q0[8]), "+v"(q0[9]), "+v"(q0[10]), "+v"(q0[11]));
+            auto pick = [&](const v2f (&q)[12], bool odd, float (&v)[16]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r * 4 + 0] = odd ? q[3 * r].y : q[3 * r].x;
+                    v[r * 4 + 1] = odd ? q[3 * r + 1].x : q[3 * r].y;
+                    v[r * 4 + 2] = odd ? q[3 * r + 1].y : q[3 * r + 1].x;
+                    v[r * 4 + 3] = odd ? q[3 * r + 2].x : q[3 * r + 1].y;
+                }
+            };
+            {
+                float v[16];
+                pick(q0, px[0].odd, v);
+                const float val = fi4_pixel(v, px[0].f, px[0].alpha, px[0].beta);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[0], 0, 0);
+            }
+#pragma unroll
+            for (int r = 1; r < 4; ++r) { FI_READ64(q1[3 * r], a1[r], 0); FI_READ64(q1[3 * r + 1], a1[r], 8); FI_READ64(q1[3 * r + 2], a1[r], 16); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]), "+v"(q1[4]), "+v"(q1[5]),
+                                                   "+v"(q1[6]), "+v"(q1[7]), "+v"(q1[8]), "+v"(q1[9]), "+v"(q1[10]), "+v"(q1[11]));
+            {
+                float v[16];
+                pick(q1, px[1].odd, v);
+                const float val = fi4_pixel(v, px[1].f, px[1].alpha, px[1].beta);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[1], 0, 0);
+            }
+        } else {
+        // a read fetches columns (0, 2) or (1, 3) of a tap row: the two halves of a register pair then belong to the left
+        // and the right quadrant, and one packed multiply-add advances both quadrant sums (same order per sum as fi4_pixel)
+        v2f q0[8], q1[8];
+        if (abl & 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q0[i] = v2f{(float)i, 1.0f}; q1[i] = v2f{2.0f, (float)i}; }
+        }
+        if (!(abl & 4)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { FI_READ2(q0[2 * r], a0[r], 0, 2); FI_READ2(q0[2 * r + 1], a0[r], 1, 3); }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { FI_READ2(q1[2 * r], a1[r], 0, 2); FI_READ2(q1[2 * r + 1], a1[r], 1, 3); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q0[4]), "+v"(q0[5]), "+v"(q0[6]), "+v"(q0[7]));
+        auto pixel = [&](const v2f (&q)[8], int p) {
+            v2f top = q[0] * F[p][0];
+            top = __builtin_elementwise_fma(q[1], F[p][1], top);
+            top = __builtin_elementwise_fma(q[2], F[p][2], top);
+            top = __builtin_elementwise_fma(q[3], F[p][3], top);
+            v2f bot = q[4] * F[p][4];
+            bot = __builtin_elementwise_fma(q[5], F[p][5], bot);
+            bot = __builtin_elementwise_fma(q[6], F[p][6], bot);
+            bot = __builtin_elementwise_fma(q[7], F[p][7], bot);
+            const float val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+            if (!(abl & 1) || val == 123456.789f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+        };
+        pixel(q0, 0);
+        if (!(abl & 4)) {
+#pragma unroll
+        for (int r = 2; r < 4; ++r) { FI_READ2(q1[2 * r], a1[r], 0, 2); FI_READ2(q1[2 * r + 1], a1[r], 1, 3); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]), "+v"(q1[4]), "+v"(q1[5]), "+v"(q1[6]), "+v"(q1[7]));
+        pixel(q1, 1);
+        }
+        pout += cs;
+    };
+#undef FI_READ2
+#undef FI_READ64
+    // prologue: the first D windows
+    const int n0 = min(D, c_end - c_begin);
+    for (int j = 0; j < n0; ++j) issue(j);
+    fi_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
+    __builtin_amdgcn_s_barrier();                               // ... in every wave
+    int c = c_begin, slot = 0;
+    for (; c + D <= last; ++c) {                                // steady state: window c + D exists
+        issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        compute(slot);
+        if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
+        if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
+        compute(slot);
+        if (c < last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int p = 0; p < FI_PX; ++p)                             // copy-through of the (rare) invalid pixels (:2814-2818)
+        if (px[p].inimg && !px[p].valid)
+            for (int cc = c_begin; cc < c_end; ++cc) out[(int64_t)cc * cs + px[p].pix] = img[(int64_t)cc * cs + px[p].pix];
+}
+
 // two 512-thread workgroups per CU (4 waves per SIMD): at most 128 VGPRs
-template <bool BLEND>
+template <bool BLEND, int MODE>
 __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
@@ -295,15 +483,27 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
         }
     }
     __syncthreads();
-    const int bx0 = box[0], by0 = box[1];
-    const bool any_valid = bx0 != INT_MAX;
+    const bool any_valid = box[0] != INT_MAX;
+    // MODE 0 (the product): the lean channel loop, or the plain one under a blend epilogue.  Development builds: 1 = the
+    // plain loop; 2 = the lean loop with aligned 8-byte tap reads (12-20 % faster on rough flow fields, where the lanes of
+    // a wave sit on many window rows and columns and bank conflicts dominate; 10 % slower on smooth ones: 16 selects per
+    // pixel and channel.  Choosing per tile inside one kernel spills inside the DMA loops).
+    const int raw_bh = any_valid ? box[3] - box[1] + 1 : 0;
+    constexpr bool use64 = MODE == 2;
+    constexpr bool lean = !BLEND && MODE != 1;
+    const int bx0 = (use64 && any_valid) ? (box[0] & ~1) : box[0], by0 = box[1];       // 8-byte reads: window columns keep the image's parity
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
-    const int bh = any_valid ? box[3] - by0 + 1 : 0;
-    const int pitch = (bw + 31) & ~31;                      // LDS row pitch: a multiple of the 32 banks
+    const int bh = raw_bh;
+    // LDS row pitch: a multiple of the 32 banks; 8-byte reads see 64 banks: = 32 mod 64
+    const int pitch = use64 ? (((bw + 31) >> 6) << 6) + 32 : (bw + 31) & ~31;
     const int n = pitch * bh;                               // <= (w+33)*(h+2): fits int for any real frame
 
 #pragma unroll
-    for (int p = 0; p < FI_PX; ++p) px[p].lbase = (T[p] - by0) * pitch + (L[p] - bx0);
+    for (int p = 0; p < FI_PX; ++p) {
+        const int lc = L[p] - bx0;
+        px[p].odd = use64 && (lc & 1);
+        px[p].lbase = (T[p] - by0) * pitch + (use64 ? (lc & ~1) : lc);
+    }
 
     const float* img = in1 + (int64_t)b * s1.b;
     float* dst = out + (int64_t)b * s1.b;
@@ -332,8 +532,9 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
     const FiWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FI_HDR;
-#define FI_RUN(K) fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
-                                     min((flags >> 8) ? (flags >> 8) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
+#define FI_RUN(K) if constexpr (lean) fi_run_channels_lean<K, use64>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); else \
+                  fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
+                                     min(((flags >> 8) & 255) ? ((flags >> 8) & 255) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
     if (kmax <= 2) FI_RUN(2);
     else if (kmax == 3) FI_RUN(3);
     else if (kmax == 4) FI_RUN(4);
@@ -351,7 +552,9 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
 using namespace vfi;
 
-// Kernel flags: bit 0 issue the next DMA before / after the compute phase; bit 1 XCD-contiguous bands of tiles;
+// Kernel flags: bit 0 issue the next DMA before / after the compute phase (plain loop); bit 1 XCD-contiguous bands of tiles;
+// bits 16-17 channel loop (development builds: 1 plain, 2 lean with 8-byte tap reads); bits 20-25 parts of the lean loop
+// switched off (development builds, timing only);
 // bits 2-3 log2 of the tiles per XCD group (default 2: four horizontally consecutive tiles on one XCD, see the
 // kernel); bits 4-5 two-dimensional groups; bits 8.. ring depth.  g_fi_groups: channel groups, 0 = chosen below.
 #define FI_DEFAULT_FLAGS 8
@@ -398,10 +601,17 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
     }
     const dim3 grid((unsigned)grid_x, (unsigned)groups, 1);
     if (blend.out)
-        hipLaunchKernelGGL(fi_forward_ori_lds<true>, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
+        hipLaunchKernelGGL((fi_forward_ori_lds<true, 0>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
                            input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
+#ifdef VFI_DEV
+#define FI_DEV_MODE(M) hipLaunchKernelGGL((fi_forward_ori_lds<false, M>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2, \
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend)
+    else if (((g_fi_flags >> 16) & 3) == 1) FI_DEV_MODE(1);   // the plain channel loop
+    else if (((g_fi_flags >> 16) & 3) == 2) FI_DEV_MODE(2);   // the lean loop with 8-byte tap reads
+#undef FI_DEV_MODE
+#endif
     else
-        hipLaunchKernelGGL(fi_forward_ori_lds<false>, grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
+        hipLaunchKernelGGL((fi_forward_ori_lds<false, 0>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
                            input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
     return launch_status();
 }
