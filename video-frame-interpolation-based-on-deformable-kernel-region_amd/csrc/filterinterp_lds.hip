@@ -59,6 +59,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
 #define FI_KTOP 15                                  // staged elements per thread and channel, at most
 #define FI_XCDS 8
+#define FI_B64_MIN_BH 32                             // bounding box from which a tile takes the aligned 8-byte tap reads
+#define FI_B64_MIN_BW 88
 #ifdef VFI_DEV
 #define FI_ABL(flags) (((flags) >> 20) & 63)        // development: parts of the lean loop switched off (wrong results, timing only)
 #else
@@ -484,13 +486,19 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     }
     __syncthreads();
     const bool any_valid = box[0] != INT_MAX;
-    // MODE 0 (the product): the lean channel loop, or the plain one under a blend epilogue.  Development builds: 1 = the
-    // plain loop; 2 = the lean loop with aligned 8-byte tap reads (12-20 % faster on rough flow fields, where the lanes of
-    // a wave sit on many window rows and columns and bank conflicts dominate; 10 % slower on smooth ones: 16 selects per
-    // pixel and channel.  Choosing per tile inside one kernel spills inside the DMA loops).
+    // MODE 0 (the product): the lean channel loop (the plain one under a blend epilogue), tap reads chosen per tile: a tall or
+    // wide bounding box marks a rough flow field, where the lanes of a wave sit on many window rows and columns and LDS bank
+    // conflicts dominate -- there the aligned 8-byte reads win (C=196 on the "quarter" field: 1.77 -> 1.61 ms; all tiles on
+    // them: 1.58); on a smooth field they lose 3-10 % to their 16 selects per pixel and channel, and its tiles keep the
+    // 4-byte reads.  Development builds: 1 = the plain loop, 2 = 8-byte reads everywhere, 3 = 4-byte reads everywhere.
     const int raw_bh = any_valid ? box[3] - box[1] + 1 : 0;
-    constexpr bool use64 = MODE == 2;
+    const int raw_bw = any_valid ? box[2] - box[0] + 1 : 0;
     constexpr bool lean = !BLEND && MODE != 1;
+    // (the 8-byte layout's pitch is = 32 mod 64 floats: a window that needs more than 10 x 512 elements with it keeps the
+    //  4-byte reads and their tighter pitch -- the two largest ring geometries are compiled for those only)
+    const int bw64 = any_valid ? box[2] - (box[0] & ~1) + 1 : 0;
+    const bool fits64 = ((((bw64 + 31) >> 6) << 6) + 32) * raw_bh <= 10 * FI_THREADS;
+    const bool use64 = lean && (MODE == 2 || (MODE == 0 && fits64 && (raw_bh >= FI_B64_MIN_BH || raw_bw >= FI_B64_MIN_BW)));
     const int bx0 = (use64 && any_valid) ? (box[0] & ~1) : box[0], by0 = box[1];       // 8-byte reads: window columns keep the image's parity
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
     const int bh = raw_bh;
@@ -532,7 +540,10 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 
     const FiWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FI_HDR;
-#define FI_RUN(K) if constexpr (lean) fi_run_channels_lean<K, use64>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); else \
+#define FI_RUN(K) if constexpr (lean && MODE == 0) { \
+        if constexpr ((K) <= 10) { if (use64) fi_run_channels_lean<K, true>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); } \
+        if (!use64) fi_run_channels_lean<K, false>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); \
+    } else if constexpr (lean) fi_run_channels_lean<K, MODE == 2>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); else \
                   fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
                                      min(((flags >> 8) & 255) ? ((flags >> 8) & 255) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
     if (kmax <= 2) FI_RUN(2);
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
 using namespace vfi;
 
 // Kernel flags: bit 0 issue the next DMA before / after the compute phase (plain loop); bit 1 XCD-contiguous bands of tiles;
-// bits 16-17 channel loop (development builds: 1 plain, 2 lean with 8-byte tap reads); bits 20-25 parts of the lean loop
+// bits 16-17 channel loop (development builds: 1 plain, 2 / 3 lean with 8- / 4-byte tap reads everywhere); bits 20-25 parts of the lean loop
 // switched off (development builds, timing only);
 // bits 2-3 log2 of the tiles per XCD group (default 2: four horizontally consecutive tiles on one XCD, see the
 // kernel); bits 4-5 two-dimensional groups; bits 8.. ring depth.  g_fi_groups: channel groups, 0 = chosen below.
@@ -608,6 +619,7 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
                            input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend)
     else if (((g_fi_flags >> 16) & 3) == 1) FI_DEV_MODE(1);   // the plain channel loop
     else if (((g_fi_flags >> 16) & 3) == 2) FI_DEV_MODE(2);   // the lean loop with 8-byte tap reads
+    else if (((g_fi_flags >> 16) & 3) == 3) FI_DEV_MODE(3);   // the lean loop with 4-byte tap reads only
 #undef FI_DEV_MODE
 #endif
     else
