@@ -51,16 +51,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 #define FI_TW 64
 #define FI_TH 16
-#define FI_PX 2                                     // pixels per thread (rows y and y + FI_TH/FI_PX)
+#ifndef FI_PX
+#define FI_PX 2                                     // pixels per thread (rows y, y + FI_TH/FI_PX, ...)
+#endif
 #define FI_THREADS (FI_TW * FI_TH / FI_PX)          // 512
 #define FI_PASS_ROWS (FI_TH / FI_PX)
+#define FI_KS (FI_PX / 2)                           // staged elements per thread scale with the pixels per thread
 #define FI_HDR 16                                   // floats at the head of the LDS array (bounding box)
 #define FI_RING_FLOATS 15984                        // LDS ring: 16000 floats = 64,000 B with the header
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
-#define FI_KTOP 15                                  // staged elements per thread and channel, at most
+#define FI_KTOP (15 * FI_KS)                        // staged elements per thread and channel, at most
 #define FI_XCDS 8
-#define FI_B64_MIN_BH 32                             // bounding box from which a tile takes the aligned 8-byte tap reads
-#define FI_B64_MIN_BW 88
+#define FI_B64_MIN_BH 34                             // bounding box from which a tile takes the aligned 8-byte tap reads
+#define FI_B64_MIN_BW 92
 #ifdef VFI_DEV
 #define FI_ABL(flags) (((flags) >> 20) & 63)        // development: parts of the lean loop switched off (wrong results, timing only)
 #else
@@ -95,9 +98,9 @@ template <int K>
 __device__ __forceinline__ void fi_wait_windows(int younger_groups) {
     switch (younger_groups) {
     case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
-    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K) : "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K < 63 ? K : 63) : "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K < 63 ? 2 * K : 63) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K < 63 ? 3 * K : 63) : "memory"); break;
     }
 }
 
@@ -107,7 +110,7 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
                                                 int c_begin, int c_end, int tid, const FiWindow& win,
                                                 const FiPixel (&px)[FI_PX], float* __restrict__ ring, int R,
                                                 int flags, const FiBlend& bl) {
-    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+    static_assert((FI_RING_FLOATS / (K * FI_THREADS) < FI_RMAX ? FI_RING_FLOATS / (K * FI_THREADS) - 2 : FI_RMAX - 2) * K <= 63, "vmcnt is a 6-bit counter");
     // Element e = tid + k*FI_THREADS of the staged window, row-major with row pitch `pitch` = bw
     // rounded up to a multiple of 32 floats: with the pitch a multiple of the 32 LDS banks a tap's
     // bank depends on its column only, so lanes of a wave whose windows sit on different rows do
@@ -222,7 +225,6 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
                                                      int c_begin, int c_end, int tid, const FiWindow& win,
                                                      const FiPixel (&px)[FI_PX], float* __restrict__ ring, int abl) {
     typedef float v2f __attribute__((ext_vector_type(2)));
-    static_assert(FI_PX == 2, "two pixels per thread");
     constexpr int NP = K * FI_THREADS;
     constexpr int R = (FI_RING_FLOATS / NP) < FI_RMAX ? (FI_RING_FLOATS / NP) : FI_RMAX;
     constexpr int D = R - 1;
@@ -274,78 +276,88 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     auto compute = [&](int slot) {
         const unsigned so = (unsigned)(slot * (NP * 4));
         const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, plane_bytes, 0x00020000);
-        unsigned a0[4], a1[4];
-        a0[0] = lb[0] + so; a1[0] = lb[1] + so;
-#pragma unroll
-        for (int r = 1; r < 4; ++r) { a0[r] = a0[r - 1] + pitch4; a1[r] = a1[r - 1] + pitch4; }
-        if constexpr (B64) {
-            // aligned 8-byte reads, three per tap row (see the plain loop): at most 15 LDS reads outstanding
-            v2f q0[12], q1[12];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { FI_READ64(q0[3 * r], a0[r], 0); FI_READ64(q0[3 * r + 1], a0[r], 8); FI_READ64(q0[3 * r + 2], a0[r], 16); }
-            FI_READ64(q1[0], a1[0], 0); FI_READ64(q1[1], a1[0], 8); FI_READ64(q1[2], a1[0], 16);
-            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q0[4]), "+v"(q0[5]),
-                                                   "+v"(q0[6]), "+v"(q0[7]), "+v"(q0[8]), "+v"(q0[9]), "+v"(q0[10]), "+v"(q0[11]));
-            auto pick = [&](const v2f (&q)[12], bool odd, float (&v)[16]) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r * 4 + 0] = odd ? q[3 * r].y : q[3 * r].x;
-                    v[r * 4 + 1] = odd ? q[3 * r + 1].x : q[3 * r].y;
-                    v[r * 4 + 2] = odd ? q[3 * r + 1].y : q[3 * r + 1].x;
-                    v[r * 4 + 3] = odd ? q[3 * r + 2].x : q[3 * r + 1].y;
-                }
-            };
-            {
-                float v[16];
-                pick(q0, px[0].odd, v);
-                const float val = fi4_pixel(v, px[0].f, px[0].alpha, px[0].beta);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[0], 0, 0);
-            }
-#pragma unroll
-            for (int r = 1; r < 4; ++r) { FI_READ64(q1[3 * r], a1[r], 0); FI_READ64(q1[3 * r + 1], a1[r], 8); FI_READ64(q1[3 * r + 2], a1[r], 16); }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]), "+v"(q1[4]), "+v"(q1[5]),
-                                                   "+v"(q1[6]), "+v"(q1[7]), "+v"(q1[8]), "+v"(q1[9]), "+v"(q1[10]), "+v"(q1[11]));
-            {
-                float v[16];
-                pick(q1, px[1].odd, v);
-                const float val = fi4_pixel(v, px[1].f, px[1].alpha, px[1].beta);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[1], 0, 0);
-            }
-        } else {
-        // a read fetches columns (0, 2) or (1, 3) of a tap row: the two halves of a register pair then belong to the left
-        // and the right quadrant, and one packed multiply-add advances both quadrant sums (same order per sum as fi4_pixel)
-        v2f q0[8], q1[8];
+        // Tap reads of pixel p come in two parts (4-byte reads: rows 0-1, then rows 2-3; 8-byte reads: row 0, then rows 1-3);
+        // before pixel p is multiplied, all of its reads and the first part of pixel p + 1's have been issued: two pixels'
+        // registers ping-pong, at most 12 (15) LDS reads are outstanding.
+        constexpr int NQ = B64 ? 12 : 8;                    // register pairs per pixel
+        constexpr int PART0 = B64 ? 3 : 4;                  // reads in the first part
+        v2f q[2][NQ];
         if (abl & 4) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { q0[i] = v2f{(float)i, 1.0f}; q1[i] = v2f{2.0f, (float)i}; }
+            for (int i = 0; i < NQ; ++i) { q[0][i] = v2f{(float)i, 1.0f}; q[1][i] = v2f{2.0f, (float)i}; }
         }
-        if (!(abl & 4)) {
+        auto reads = [&](auto P, auto H) {
+            constexpr int p = decltype(P)::value, h = decltype(H)::value;
+            if (abl & 4) return;
+            v2f (&d)[NQ] = q[p & 1];
+            if constexpr (B64) {
+                if constexpr (h == 0) {
+                    const unsigned a = lb[p] + so;
+                    FI_READ64(d[0], a, 0); FI_READ64(d[1], a, 8); FI_READ64(d[2], a, 16);
+                } else {
+                    unsigned a = lb[p] + so;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { FI_READ2(q0[2 * r], a0[r], 0, 2); FI_READ2(q0[2 * r + 1], a0[r], 1, 3); }
+                    for (int r = 1; r < 4; ++r) { a += pitch4; FI_READ64(d[3 * r], a, 0); FI_READ64(d[3 * r + 1], a, 8); FI_READ64(d[3 * r + 2], a, 16); }
+                }
+            } else {
+                // a read fetches columns (0, 2) or (1, 3) of a tap row: the two halves of a register pair then belong to the
+                // left and the right quadrant, and one packed multiply-add advances both quadrant sums
+                unsigned a = lb[p] + so + (h ? 2u * pitch4 : 0u);
+                FI_READ2(d[4 * h], a, 0, 2); FI_READ2(d[4 * h + 1], a, 1, 3);
+                a += pitch4;
+                FI_READ2(d[4 * h + 2], a, 0, 2); FI_READ2(d[4 * h + 3], a, 1, 3);
+            }
+        };
+        auto arrived = [&](auto P) {        // waits until pixel p's reads are back: what may stay outstanding is the part issued after them
+            constexpr int p = decltype(P)::value;
+            constexpr int later = (p + 1 < FI_PX) ? PART0 : 0;
+            v2f (&d)[NQ] = q[p & 1];
+            if constexpr (B64)
+                asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                         "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]) : "n"(later));
+            else
+                asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                        "+v"(d[6]), "+v"(d[7]) : "n"(later));
+        };
+        auto pixel = [&](auto P) {
+            constexpr int p = decltype(P)::value;
+            const v2f (&d)[NQ] = q[p & 1];
+            float val;
+            if constexpr (B64) {
+                const bool odd = px[p].odd;
+                float v[16];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { FI_READ2(q1[2 * r], a1[r], 0, 2); FI_READ2(q1[2 * r + 1], a1[r], 1, 3); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q0[4]), "+v"(q0[5]), "+v"(q0[6]), "+v"(q0[7]));
-        auto pixel = [&](const v2f (&q)[8], int p) {
-            v2f top = q[0] * F[p][0];
-            top = __builtin_elementwise_fma(q[1], F[p][1], top);
-            top = __builtin_elementwise_fma(q[2], F[p][2], top);
-            top = __builtin_elementwise_fma(q[3], F[p][3], top);
-            v2f bot = q[4] * F[p][4];
-            bot = __builtin_elementwise_fma(q[5], F[p][5], bot);
-            bot = __builtin_elementwise_fma(q[6], F[p][6], bot);
-            bot = __builtin_elementwise_fma(q[7], F[p][7], bot);
-            const float val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+                for (int r = 0; r < 4; ++r) {
+                    v[r * 4 + 0] = odd ? d[3 * r].y : d[3 * r].x;
+                    v[r * 4 + 1] = odd ? d[3 * r + 1].x : d[3 * r].y;
+                    v[r * 4 + 2] = odd ? d[3 * r + 1].y : d[3 * r + 1].x;
+                    v[r * 4 + 3] = odd ? d[3 * r + 2].x : d[3 * r + 1].y;
+                }
+                val = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+            } else {
+                v2f top = d[0] * F[p][0];                   // (same order per quadrant sum as fi4_pixel)
+                top = __builtin_elementwise_fma(d[1], F[p][1], top);
+                top = __builtin_elementwise_fma(d[2], F[p][2], top);
+                top = __builtin_elementwise_fma(d[3], F[p][3], top);
+                v2f bot = d[4] * F[p][4];
+                bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
+                bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
+                bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
+                val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+            }
             if (!(abl & 1) || val == 123456.789f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
         };
-        pixel(q0, 0);
-        if (!(abl & 4)) {
-#pragma unroll
-        for (int r = 2; r < 4; ++r) { FI_READ2(q1[2 * r], a1[r], 0, 2); FI_READ2(q1[2 * r + 1], a1[r], 1, 3); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]), "+v"(q1[4]), "+v"(q1[5]), "+v"(q1[6]), "+v"(q1[7]));
-        pixel(q1, 1);
-        }
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        reads(I0{}, I0{}); reads(I0{}, I1{});
+        if constexpr (FI_PX > 1) reads(I1{}, I0{});
+        static_for<0, FI_PX>([&](auto P) {
+            constexpr int p = decltype(P)::value;
+            arrived(P);
+            pixel(P);
+            if constexpr (p + 1 < FI_PX) reads(std::integral_constant<int, p + 1>{}, I1{});
+            if constexpr (p + 2 < FI_PX) reads(std::integral_constant<int, p + 2>{}, I0{});
+        });
         pout += cs;
     };
 #undef FI_READ2
@@ -379,7 +391,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
 
 // two 512-thread workgroups per CU (4 waves per SIMD): at most 128 VGPRs
 template <bool BLEND, int MODE>
-__global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
+__global__ __launch_bounds__(FI_THREADS, 8 / FI_PX) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3,
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     // (the 8-byte layout's pitch is = 32 mod 64 floats: a window that needs more than 10 x 512 elements with it keeps the
     //  4-byte reads and their tighter pitch -- the two largest ring geometries are compiled for those only)
     const int bw64 = any_valid ? box[2] - (box[0] & ~1) + 1 : 0;
-    const bool fits64 = ((((bw64 + 31) >> 6) << 6) + 32) * raw_bh <= 10 * FI_THREADS;
+    const bool fits64 = ((((bw64 + 31) >> 6) << 6) + 32) * raw_bh <= 10 * FI_KS * FI_THREADS;
     const bool use64 = lean && (MODE == 2 || (MODE == 0 && fits64 && (raw_bh >= FI_B64_MIN_BH || raw_bw >= FI_B64_MIN_BW)));
     const int bx0 = (use64 && any_valid) ? (box[0] & ~1) : box[0], by0 = box[1];       // 8-byte reads: window columns keep the image's parity
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
@@ -541,21 +553,21 @@ __global__ __launch_bounds__(FI_THREADS, 4) void fi_forward_ori_lds(
     const FiWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FI_HDR;
 #define FI_RUN(K) if constexpr (lean && MODE == 0) { \
-        if constexpr ((K) <= 10) { if (use64) fi_run_channels_lean<K, true>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); } \
+        if constexpr ((K) <= 10 * FI_KS) { if (use64) fi_run_channels_lean<K, true>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); } \
         if (!use64) fi_run_channels_lean<K, false>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); \
     } else if constexpr (lean) fi_run_channels_lean<K, MODE == 2>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); else \
                   fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
                                      min(((flags >> 8) & 255) ? ((flags >> 8) & 255) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
-    if (kmax <= 2) FI_RUN(2);
-    else if (kmax == 3) FI_RUN(3);
-    else if (kmax == 4) FI_RUN(4);
-    else if (kmax == 5) FI_RUN(5);
-    else if (kmax == 6) FI_RUN(6);
-    else if (kmax == 7) FI_RUN(7);
-    else if (kmax == 8) FI_RUN(8);
-    else if (kmax <= 10) FI_RUN(10);
-    else if (kmax <= 12) FI_RUN(12);
-    else FI_RUN(15);
+    if (kmax <= 2 * FI_KS) FI_RUN(2 * FI_KS);
+    else if (kmax <= 3 * FI_KS) FI_RUN(3 * FI_KS);
+    else if (kmax <= 4 * FI_KS) FI_RUN(4 * FI_KS);
+    else if (kmax <= 5 * FI_KS) FI_RUN(5 * FI_KS);
+    else if (kmax <= 6 * FI_KS) FI_RUN(6 * FI_KS);
+    else if (kmax <= 7 * FI_KS) FI_RUN(7 * FI_KS);
+    else if (kmax <= 8 * FI_KS) FI_RUN(8 * FI_KS);
+    else if (kmax <= 10 * FI_KS) FI_RUN(10 * FI_KS);
+    else if (kmax <= 12 * FI_KS) FI_RUN(12 * FI_KS);
+    else FI_RUN(15 * FI_KS);
 #undef FI_RUN
 }
 
