@@ -108,6 +108,27 @@ def test_filterinterp_forward_bit_exact(torch_mod, cabi, oracle, B, C, H, W, flo
         assert close(out, strict)
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 9, 23])
+def test_filterinterp_forward_mixed_tiles_and_short_channel_ranges(torch_mod, cabi, oracle, C):
+    """One frame whose 64x16 tiles take different paths of the staged kernel: smooth tiles (4-byte tap reads), rough tiles
+    whose bounding box is tall / wide (aligned 8-byte tap reads, odd and even window origins, negative window corners at
+    the frame border), tiles too rough for the 8-byte pitch, and a band that leaves the frame (copy-through).  Channel
+    counts below, at and above the ring depth: the steady-state loop, the tail loop and both together.  Bit-exact."""
+    torch = torch_mod
+    rng = np.random.default_rng(100 + C)
+    B, H, W = 1, 96, 448
+    img = rng.random((B, C, H, W), dtype=f32)
+    filt = rng.random((B, 16, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    flow[:, :, :, 128:256] += rng.uniform(-9, 9, (B, 2, H, 128)).astype(f32)         # rough: boxes ~ 16 + 21 rows
+    flow[:, :, :, 256:320] += rng.uniform(-30, 30, (B, 2, H, 64)).astype(f32)        # too rough for the wide pitch
+    flow[:, 0, 40:56, 330:400] = 1000.0                                              # invalid: copy-through
+    flow[:, :, :16, :64] = rng.uniform(-9, 0, (B, 2, 16, 64)).astype(f32)            # rough at the top-left corner
+    ref = oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1)
+    out = cpu(run_fi(torch, cabi, gpu(torch, img), gpu(torch, flow), gpu(torch, filt)))
+    assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
+
+
 @pytest.mark.parametrize("fs", [2, 3, 5, 6])
 def test_filterinterp_forward_other_filter_sizes(torch_mod, cabi, oracle, fs):
     torch = torch_mod

@@ -118,11 +118,21 @@ __device__ __forceinline__ void f16_wait_windows(int younger_groups) {
 __device__ __forceinline__ float f16_lo(unsigned d) { return __half2float(__ushort_as_half((unsigned short)(d & 0xffffu))); }
 __device__ __forceinline__ float f16_hi(unsigned d) { return __half2float(__ushort_as_half((unsigned short)(d >> 16))); }
 
+// Channel loop of one workgroup, written like fi_run_channels_lean (filterinterp_lds.hip: what bounds this loop is the
+// instruction count): ring geometry a compile-time function of K and one constant s_waitcnt in the steady state, running
+// plane descriptors, M0 formed on the scalar unit, tap reads as asm with two lgkmcnt waits per channel and the second
+// pixel's first rows in flight under the first pixel's arithmetic, range-checked buffer stores.
 template <int K>
 __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img, __half* __restrict__ out, int64_t cs,
                                                  int c_begin, int c_end, int tid, const F16Window& win,
-                                                 const F16Pixel (&px)[F16_PX], unsigned* __restrict__ ring, int R) {
-    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+                                                 const F16Pixel (&px)[F16_PX], unsigned* __restrict__ ring) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    static_assert(F16_PX == 2, "two pixels per thread");
+    constexpr int NP = K * F16_THREADS;                     // dwords per ring slot
+    constexpr int R = (F16_RING_DWORDS / NP) < F16_RMAX ? (F16_RING_DWORDS / NP) : F16_RMAX;
+    constexpr int D = R - 1;
+    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    if (c_begin >= c_end) return;
     // dword e = tid + k*F16_THREADS of the staged window, row-major, `pitch` dwords per row; rows
     // clamped to the image, columns never out of it; pad dwords get an out-of-range offset (the
     // load returns 0 without touching memory)
@@ -136,57 +146,90 @@ __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img,
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
     }
     const int plane_bytes = (2 * ((win.h - 1) * win.hs + win.w) + 3) & ~3;
-    constexpr int NP = K * F16_THREADS;                     // dwords per ring slot
-    const int D = R - 1;
-    auto issue = [&](int c, int slot) {
-        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
-        unsigned* l = ring + slot * NP + tid;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(f16_lptr_t)ring;
+    const unsigned pitch4 = 4u * (unsigned)win.pitch;
+    unsigned lb[F16_PX], sh[F16_PX], soff[F16_PX];
+#pragma unroll
+    for (int p = 0; p < F16_PX; ++p) {
+        lb[p] = ring_lds + 4u * (unsigned)(px[p].lbase >> 1);
+        sh[p] = (unsigned)(px[p].lbase & 1) * 16u;
+        soff[p] = px[p].valid ? 2u * px[p].pix : 0x80000000u;   // (an invalid pixel's store is dropped by the range check)
+    }
+    const int last = c_end - 1;
+    const __half* pdma = img + (int64_t)c_begin * cs;
+    __half* pout = out + (int64_t)c_begin * cs;
+    auto issue = [&](int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
+        unsigned* l = ring + slot * NP + wave_first;
 #pragma unroll
         for (int k = 0; k < K; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (f16_lptr_t)(l + k * F16_THREADS), 4, goff[k], 0, 0, 0);
+        pdma += cs;
     };
-    auto compute = [&](int c, int slot) {
-        __half* o = out + (int64_t)c * cs;
-        const unsigned* base = ring + slot * NP;
+#define F16_READ2(dst, addr) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(dst) : "v"(addr))
+#define F16_READ1(dst, addr) asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(dst) : "v"(addr))
+    auto compute = [&](int slot) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, plane_bytes, 0x00020000);
+        v2u a01[2][4];          // dwords 0, 1 of the four tap rows, two pixels
+        unsigned a2[2][4];      // dword 2
+        auto reads = [&](int p, int r0) {                   // rows r0, r0 + 1 of pixel p
+            unsigned a = lb[p] + so + (r0 ? 2u * pitch4 : 0u);
+            F16_READ2(a01[p][r0], a); F16_READ1(a2[p][r0], a);
+            a += pitch4;
+            F16_READ2(a01[p][r0 + 1], a); F16_READ1(a2[p][r0 + 1], a);
+        };
+        auto pixel = [&](int p) {
+            float acc = 0.0f;
 #pragma unroll
-        for (int p = 0; p < F16_PX; ++p) {
-            if (px[p].valid) {
-                const unsigned* t = base + (px[p].lbase >> 1);
-                const unsigned sh = (unsigned)(px[p].lbase & 1) * 16u;
-                float acc = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned d0 = t[r * win.pitch], d1 = t[r * win.pitch + 1], d2 = t[r * win.pitch + 2];
-                    // ({d1,d0} >> sh) and ({d2,d1} >> sh): the four taps as two packed pairs
-                    const unsigned e0 = __builtin_amdgcn_alignbit(d1, d0, sh), e1 = __builtin_amdgcn_alignbit(d2, d1, sh);
-                    acc = fmaf(f16_lo(e0), px[p].g[r * 4 + 0], acc);
-                    acc = fmaf(f16_hi(e0), px[p].g[r * 4 + 1], acc);
-                    acc = fmaf(f16_lo(e1), px[p].g[r * 4 + 2], acc);
-                    acc = fmaf(f16_hi(e1), px[p].g[r * 4 + 3], acc);
-                }
-                o[px[p].pix] = f16_store_value(acc);
+            for (int r = 0; r < 4; ++r) {
+                // ({d1,d0} >> sh) and ({d2,d1} >> sh): the four taps as two packed pairs
+                const unsigned e0 = __builtin_amdgcn_alignbit(a01[p][r].y, a01[p][r].x, sh[p]);
+                const unsigned e1 = __builtin_amdgcn_alignbit(a2[p][r], a01[p][r].y, sh[p]);
+                acc = fmaf(f16_lo(e0), px[p].g[r * 4 + 0], acc);
+                acc = fmaf(f16_hi(e0), px[p].g[r * 4 + 1], acc);
+                acc = fmaf(f16_lo(e1), px[p].g[r * 4 + 2], acc);
+                acc = fmaf(f16_hi(e1), px[p].g[r * 4 + 3], acc);
             }
-        }
+            __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f16_store_value(acc)), oplane, soff[p], 0, 0);
+        };
+        reads(0, 0); reads(0, 2); reads(1, 0);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a01[0][0]), "+v"(a01[0][1]), "+v"(a01[0][2]), "+v"(a01[0][3]),
+                                               "+v"(a2[0][0]), "+v"(a2[0][1]), "+v"(a2[0][2]), "+v"(a2[0][3]));
+        pixel(0);
+        reads(1, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01[1][0]), "+v"(a01[1][1]), "+v"(a01[1][2]), "+v"(a01[1][3]),
+                                               "+v"(a2[1][0]), "+v"(a2[1][1]), "+v"(a2[1][2]), "+v"(a2[1][3]));
+        pixel(1);
+        pout += cs;
     };
-
-    if (c_begin >= c_end) return;
-    const int last = c_end - 1;
-    for (int j = 0; j < D; ++j)
-        if (c_begin + j <= last) issue(c_begin + j, j);
-    f16_wait_windows<K>(min(c_begin + D - 1, last) - c_begin);
-    __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int c = c_begin; c <= last; ++c) {
-        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
-        compute(c, slot);
-        if (c < last) f16_wait_windows<K>(min(c + D, last) - (c + 1));
+#undef F16_READ2
+#undef F16_READ1
+    const int n0 = min(D, c_end - c_begin);
+    for (int j = 0; j < n0; ++j) issue(j);
+    f16_wait_windows<K>(n0 - 1);                                // the first window has landed ...
+    __builtin_amdgcn_s_barrier();                               // ... in every wave
+    int c = c_begin, slot = 0;
+    for (; c + D <= last; ++c) {                                // steady state: window c + D exists
+        issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        compute(slot);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
         __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
+        compute(slot);
+        if (c < last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
 #pragma unroll
     for (int p = 0; p < F16_PX; ++p)
         if (px[p].inimg && !px[p].valid)
-            for (int c = c_begin; c < c_end; ++c) out[(int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+            for (int cc = c_begin; cc < c_end; ++cc) out[(int64_t)cc * cs + px[p].pix] = img[(int64_t)cc * cs + px[p].pix];
 }
 
 __global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
@@ -197,7 +240,10 @@ __global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
     __shared__ unsigned lds[F16_HDR + F16_RING_DWORDS];
     int* box = reinterpret_cast<int*>(lds);
 
-    const int tile = blockIdx.x;
+    // four horizontally consecutive tiles on one XCD (workgroups are dealt round-robin to the 8 XCDs): the 128-byte lines
+    // a window shares with its left and right neighbours are fetched into one L2 (filterinterp_lds.hip)
+    const int xs = blockIdx.x % 8, kx = blockIdx.x / 8;
+    const int tile = ((kx / 4) * 8 + xs) * 4 + (kx % 4);
     if (tile >= ntiles) return;
     const int b = tile / (tiles_x * tiles_y);
     const int trem = tile - b * (tiles_x * tiles_y);
@@ -306,8 +352,7 @@ __global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
 
     const F16Window win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     unsigned* ring = lds + F16_HDR;
-#define F16_RUN(K) f16_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
-                                       min(F16_RMAX, F16_RING_DWORDS / ((K) * F16_THREADS)))
+#define F16_RUN(K) f16_run_channels<K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring)
     if (kmax <= 2) F16_RUN(2);
     else if (kmax == 3) F16_RUN(3);
     else if (kmax == 4) F16_RUN(4);
@@ -361,7 +406,8 @@ extern "C" int vfi_filterinterp_forward_ori_f16(const void* input1, const float*
     }
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
-    hipLaunchKernelGGL(fi_forward_ori_lds_f16, dim3((unsigned)ntiles, (unsigned)groups, 1), dim3(F16_THREADS, 1, 1), 0,
+    const int grid_x = ((ntiles + 31) / 32) * 32;                   // whole groups of 8 XCDs x 4 tiles
+    hipLaunchKernelGGL(fi_forward_ori_lds_f16, dim3((unsigned)grid_x, (unsigned)groups, 1), dim3(F16_THREADS, 1, 1), 0,
                        (hipStream_t)stream, (const __half*)input1, input2, input3, (__half*)output, channel, h, w, s1, s2,
                        s3, tiles_x, tiles_y, ntiles, ch_per_group);
     return launch_status();
