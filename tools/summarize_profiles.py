@@ -85,7 +85,7 @@ for model in ("smooth", "quarter"):
     rd = pmc["pmc_%s_TCC_EA0_RDREQ_sum" % model][kn] * 128.0
     wk = [k for k in pmc["pmc_%s_WRITE_SIZE" % model] if k.endswith("WRITE_SIZE")][0]
     wr = pmc["pmc_%s_WRITE_SIZE" % model][wk] * 1024.0
-    entries.append({"h": H, "w": W, "flow_model": model, "direct": False, "kernel": kn.split(" ")[0],
+    entries.append({"h": H, "w": W, "flow_model": model, "direct": False, "kernel": kn.rsplit(" ", 1)[0],
                     "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                     "algorithmic_bytes": 1640.0 * PX, "ratio": round((rd + wr) / (1640.0 * PX), 3),
                     "source": "profiles/%s_fi196_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
