@@ -217,6 +217,22 @@ def test_bench_launcher_starts_its_own_ranks():
     assert res["ms_per_step"] >= 20.0 * 0.9
 
 
+def test_bench_runs_as_ranks_under_torch_distributed_run():
+    """the driver's N > 1 command: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- bench.py
+    finds RANK / WORLD_SIZE in the environment, does not start ranks of its own, and rank 0 prints the one JSON line."""
+    import json
+    from vfidkr_amd import runner
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(runner.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "3", "--warmup", "1", "--stub-step", "0.02"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["ms_per_step"] >= 20.0 * 0.9
+
+
 def test_bench_launcher_fails_cleanly_without_gpus():
     """on a box with fewer GPUs than --gpus the parent says so and exits non-zero before starting anything;
     a rank that dies makes the parent exit non-zero too."""

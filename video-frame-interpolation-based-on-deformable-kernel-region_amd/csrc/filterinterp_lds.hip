@@ -59,7 +59,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_KS (FI_PX / 2)                           // staged elements per thread scale with the pixels per thread
 #define FI_HDR 16                                   // floats at the head of the LDS array (bounding box)
 #define FI_RING_FLOATS 15984                        // LDS ring: 16000 floats = 64,000 B with the header
+#ifndef FI_RMAX
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
+#endif
 #define FI_KTOP (15 * FI_KS)                        // staged elements per thread and channel, at most
 #define FI_XCDS 8
 #define FI_B64_MIN_BH 34                             // bounding box from which a tile takes the aligned 8-byte tap reads
