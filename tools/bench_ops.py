@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-op timing on the GPU (HIP events on the launch stream), for kernel development.
 
-    python tools/bench_ops.py [--ops fi196,fi3,proj,dproj,corr,corr16] [--flows smooth,quarter] [--iters 20]
+    python tools/bench_ops.py [--ops fi196,fi3,fi196h,fitypes,proj,dproj,corr,corr16,glue] [--flows smooth,quarter] [--iters 20]
 Prints one line per (op, flow): mean ms and algorithmic GB/s (SURVEY.md 8d byte counts).
 """
 import argparse
