@@ -395,13 +395,16 @@ extern "C" int vfi_filterinterp_forward_ori_f16(const void* input1, const float*
     const int ntiles = (int)nt;
     // split the channel range over blockIdx.y when that shortens the tail (as the fp32 kernel)
     const int slots = device_cu_count() * 2;
+    // Cost of g channel groups per tile (blockIdx.y), in channels: a workgroup pays ~4.3 channels' worth of prologue (flow +
+    // 16 filter planes, bounding box, first window); r = workgroups per slot -- half a round of tail on average, and the
+    // more workgroups a slot runs, the better their unequal durations even out (they are dealt to whichever slot frees
+    // first).  Fitted to launches timed in isolation (tools/fi_isolated.py; 1080p, C=196: 1 group 1.12 ms, 2 1.00-1.03,
+    // 3 0.99, 4 1.00, 8 1.08).
     int best_groups = 1;
     double best_cost = 0.0;
-    for (int g = 1; g <= 8 && g <= channel; g *= 2) {
-        const double wgs = (double)ntiles * g;
-        const double tail = ceil(wgs / slots) * slots / wgs;
-        const double bytes = (72.0 * g + 4.0 * channel) / (72.0 + 4.0 * channel);
-        const double cost = tail * bytes;
+    for (int g = 1; g <= 8 && g <= channel; ++g) {
+        const double r = (double)ntiles * g / slots;
+        const double cost = (channel + 4.3 * g) * ((r + 0.5) / r) * (1.0 + 0.25 / r);
         if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
     }
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
