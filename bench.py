@@ -13,7 +13,8 @@ Workloads
            6 x DepthFlowProjection   (2 directions x t in {0.25,0.5,0.75}; fillhole=1)
            6 x FilterInterpolation   on the 196-channel context tensor
            6 x FilterInterpolation   on the 3-channel frame
-      and yields 3 interpolated frames.  Weak scaling: every rank has its own pair.
+      in the reference's order (all correlations, all six projections, then per time offset the two context warps
+      and the two frame warps), and yields 3 interpolated frames.  Weak scaling: every rank has its own pair.
   vimeo64 (BASELINE.json configs[3]): 64 Vimeo-90K triplets (256x448 padded to 320x512) through the DAIN x2 hot
       path (per pair 10 correlation + 2 FlowProjection + 2 FilterInterpolation C=3, networks/DAIN.py:198-238), the
       64 pairs sharded over the ranks with runner.shard_pairs; one STEP = every rank's shard once = 64 frames.
@@ -93,6 +94,8 @@ class SlowmoPair:
         self.corr = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(1, h, w, gen)] for _ in range(2)]
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)      # noqa: E731
         self.count, self.proj = e(1, 1, h, w), e(1, 2, h, w)
+        # FlowProject returns one projected flow per direction and time offset, all made before the first warp
+        self.projs = [[e(1, 2, h, w) for _ in TIMES] for _ in range(2)]
         self.out_ctx, self.out_img = e(1, 196, h, w), e(1, 3, h, w)
         self.gen = gen
 
@@ -241,20 +244,26 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
         assert err == 0, err
 
     def step(i, record=False):
+        # the reference's order (networks/DAIN_slowmotion.py:147-171): both flow networks (their correlations), FlowProject
+        # of both directions for every time offset, then per time offset FilterInterpolate_ctx and FilterInterpolate
         for d in range(2):
             for a, b in wl.corr[d]:
                 cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+        for d in range(2):
             for ti in range(len(TIMES)):
-                err = cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, wl.proj, 1)
+                err = cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, wl.projs[d][ti], 1)
                 assert err == 0, err
+        for ti in range(len(TIMES)):
+            for d in range(2):
                 if record:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                fi(wl.ctx[d], wl.proj, wl.filters[d], wl.out_ctx)
+                fi(wl.ctx[d], wl.projs[d][ti], wl.filters[d], wl.out_ctx)
                 if record:
                     e1.record()
                     fi196_events.append((e0, e1))
-                fi(wl.frames[d], wl.proj, wl.filters[d], wl.out_img)
+            for d in range(2):
+                fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img)
 
     for i in range(args.warmup):
         step(i)
@@ -384,16 +393,20 @@ def fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank):
         for d in range(2):
             for a, b in wl.corr[d]:
                 cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+        for d in range(2):
             for ti in range(len(TIMES)):
-                assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, wl.proj, 1) == 0
+                assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, wl.projs[d][ti], 1) == 0
+        for ti in range(len(TIMES)):
+            for d in range(2):
                 if record:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                assert cabi.filterinterp_forward_ori_f16(wl.ctx[d], wl.proj, wl.filters[d], wl.out_ctx, direct=args.direct) == 0
+                assert cabi.filterinterp_forward_ori_f16(wl.ctx[d], wl.projs[d][ti], wl.filters[d], wl.out_ctx, direct=args.direct) == 0
                 if record:
                     e1.record()
                     events.append((e0, e1))
-                assert cabi.filterinterp_forward_ori_f16(wl.frames[d], wl.proj, wl.filters[d], wl.out_img, direct=args.direct) == 0
+            for d in range(2):
+                assert cabi.filterinterp_forward_ori_f16(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img, direct=args.direct) == 0
 
     for i in range(3):
         step(i)
@@ -418,7 +431,7 @@ def shared_window_measurement(torch, cabi, wl, dev, args):
     FilterInterpolation calls: same outputs bit for bit, 3224 instead of 3 x 1640 algorithmic bytes per pixel.  Reported
     beside the headline, whose step keeps the reference's call sequence."""
     nt = len(TIMES)
-    projs = [[torch.empty_like(wl.proj) for _ in range(nt)] for _ in range(2)]
+    projs = wl.projs
     outs = [torch.empty_like(wl.out_ctx) for _ in range(nt)]
     events = []
 
@@ -426,8 +439,10 @@ def shared_window_measurement(torch, cabi, wl, dev, args):
         for d in range(2):
             for a, b in wl.corr[d]:
                 cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+        for d in range(2):
             for ti in range(nt):
                 assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], wl.count, projs[d][ti], 1) == 0
+        for d in range(2):
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
