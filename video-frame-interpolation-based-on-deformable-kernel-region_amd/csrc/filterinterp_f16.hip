@@ -394,19 +394,7 @@ extern "C" int vfi_filterinterp_forward_ori_f16(const void* input1, const float*
                                                        filter_channels, s1, s2, s3, stream);
     const int ntiles = (int)nt;
     // split the channel range over blockIdx.y when that shortens the tail (as the fp32 kernel)
-    const int slots = device_cu_count() * 2;
-    // Cost of g channel groups per tile (blockIdx.y), in channels: a workgroup pays ~4.3 channels' worth of prologue (flow +
-    // 16 filter planes, bounding box, first window); r = workgroups per slot -- half a round of tail on average, and the
-    // more workgroups a slot runs, the better their unequal durations even out (they are dealt to whichever slot frees
-    // first).  Fitted to launches timed in isolation (tools/fi_isolated.py; 1080p, C=196: 1 group 1.12 ms, 2 1.00-1.03,
-    // 3 0.99, 4 1.00, 8 1.08).
-    int best_groups = 1;
-    double best_cost = 0.0;
-    for (int g = 1; g <= 8 && g <= channel; ++g) {
-        const double r = (double)ntiles * g / slots;
-        const double cost = (channel + 4.3 * g) * ((r + 0.5) / r) * (1.0 + 0.25 / r);
-        if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
-    }
+    const int best_groups = fi_channel_groups(ntiles, channel, 4.3);
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
     const int grid_x = ((ntiles + 31) / 32) * 32;                   // whole groups of 8 XCDs x 4 tiles

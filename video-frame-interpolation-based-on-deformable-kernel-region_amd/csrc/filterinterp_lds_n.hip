@@ -230,19 +230,8 @@ extern "C" int vfi_filterinterp_forward_ori_lds_n(const float* input1, const flo
     const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
     if (nt > INT_MAX) return -1;
     const int ntiles = (int)nt;
-    // channel groups over blockIdx.y when that shortens the tail (two workgroups per CU at a time); every extra
-    // group re-reads flow + filter next to 8 B/pixel/channel of image traffic
-    const int slots = device_cu_count() * 2;
-    const double fixed = 4.0 * (2 + fs * fs);
-    int best_groups = 1;
-    double best_cost = 0.0;
-    for (int g = 1; g <= 8 && g <= channel; g *= 2) {
-        const double wgs = (double)ntiles * g;
-        const double tail = ceil(wgs / slots) * slots / wgs;
-        const double bytes = (fixed * g + 8.0 * channel) / (fixed + 8.0 * channel);
-        const double cost = tail * bytes;
-        if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
-    }
+    // (the prologue reads flow + fs x fs filter planes: ~4.3 channels' worth at fs = 4)
+    const int best_groups = fi_channel_groups(ntiles, channel, 4.3 * (2 + fs * fs) / 18.0);
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
     const dim3 grid((unsigned)ntiles, (unsigned)groups, 1), block(FN_THREADS, 1, 1);

@@ -308,18 +308,8 @@ extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const flo
     if (nt > (1 << 28)) return VFI_ERR_SHAPE;
     const int ntiles = (int)nt;
     const int per_xcd = (((ntiles + FM_XCDS - 1) / FM_XCDS) + 3) & ~3;          // whole groups of four tiles
-    // channel groups over blockIdx.y when that shortens the tail (filterinterp_lds.hip); every extra group re-reads
-    // the flows and the 16 filter planes
-    const int slots = device_cu_count() * 2;
-    int best_groups = 1;
-    double best_cost = 0.0;
-    for (int g = 1; g <= 8 && g <= channel; g *= 2) {
-        const double wgs = (double)ntiles * g;
-        const double tail = ceil(wgs / slots) * slots / wgs;
-        const double fixed = 64.0 + 8.0 * nflows, per_ch = 4.0 + 4.0 * nflows;
-        const double cost = tail * (fixed * g + per_ch * channel) / (fixed + per_ch * channel);
-        if (g == 1 || cost < best_cost) { best_cost = cost; best_groups = g; }
-    }
+    // (one prologue for nflows outputs per channel)
+    const int best_groups = fi_channel_groups(ntiles, channel, 4.3 * (1.0 + 0.3 * (nflows - 1)) / nflows);
     const int ch_per_group = (channel + best_groups - 1) / best_groups;
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
     FmPtrs ptr;

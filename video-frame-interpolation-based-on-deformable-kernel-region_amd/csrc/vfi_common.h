@@ -74,6 +74,13 @@ inline dim3 pixel_grid(int w, int h, int batch) {
 
 // compute units of the CURRENT device (cached per device id)
 int device_cu_count();
+// How many channel groups (blockIdx.y) the staged FilterInterpolation kernels split a tile's channel range into.
+// Cost of g groups, in channels: a workgroup pays `prologue` channels' worth before its first channel (flow, filter, bounding
+// box, first window); a launch leaves half a round of its slots (2 workgroups per CU) idle at the end on average; and the
+// more workgroups a slot runs, the better their unequal durations even out (they go to whichever slot frees first).
+// Fitted to launches timed in isolation (tools/fi_isolated.py; fs=4, 1080p, C=196: 1 group 1.12 ms, 2 1.00-1.03, 3 0.99,
+// 4 1.00, 8 1.08).
+int fi_channel_groups(int ntiles, int channel, double prologue);
 
 // Deterministic image gradients.  The reference scatters the image gradient of its warping layers with fp32 atomics
 // (filterinterpolation_cuda_kernel.cu:2890-2942, interpolation_cuda_kernel.cu:154-157): the sum depends on the order the

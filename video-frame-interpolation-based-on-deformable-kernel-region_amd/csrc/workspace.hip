@@ -111,6 +111,18 @@ int device_cu_count() {
     return cus[dev];
 }
 
+int fi_channel_groups(int ntiles, int channel, double prologue) {
+    const int slots = device_cu_count() * 2;
+    int best = 1;
+    double best_cost = 0.0;
+    for (int g = 1; g <= 8 && g <= channel; ++g) {
+        const double r = (double)ntiles * g / slots;
+        const double cost = (channel + prologue * g) * ((r + 0.5) / r) * (1.0 + 0.25 / r);
+        if (g == 1 || cost < best_cost) { best_cost = cost; best = g; }
+    }
+    return best;
+}
+
 }  // namespace vfi
 
 using namespace vfi;
