@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32",
                     help="slowmo1080: f16 = BASELINE.json configs[2], frames / context / correlation features and their "
                          "outputs stored as fp16, flows, filters, depth and all arithmetic fp32")
+    ap.add_argument("--vimeo-batch", type=int, default=3, help="vimeo64: triplets per call (the reference's PWC-Net allows 3)")
     ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
@@ -110,18 +111,19 @@ class SlowmoPair:
 
 
 class VimeoPair:
-    """One 256x448 triplet's tensors for the DAIN x2 hot path (padded 320x512)."""
+    """B 256x448 triplets' tensors for the DAIN x2 hot path (padded 320x512), one batch per call."""
 
-    def __init__(self, torch, S, dev, seed):
+    def __init__(self, torch, S, dev, seed, batch=1):
         gen = S.generator(seed)
         h, w = S.padded_size(256, 448)
-        self.h, self.w = h, w
-        self.frames = [S.frames(1, h, w, gen).to(dev) for _ in range(2)]
-        self.filters = [S.filters(1, h, w, gen).to(dev) for _ in range(2)]
-        self.flows = [(S.flow(1, h, w, 2.0, gen, "smooth") * 0.5).contiguous().to(dev) for _ in range(2)]   # time_offset 0.5
-        self.corr = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(1, h, w, gen)] for _ in range(2)]
+        self.h, self.w, self.batch = h, w, batch
+        B = batch
+        self.frames = [S.frames(B, h, w, gen).to(dev) for _ in range(2)]
+        self.filters = [S.filters(B, h, w, gen).to(dev) for _ in range(2)]
+        self.flows = [(S.flow(B, h, w, 2.0, gen, "smooth") * 0.5).contiguous().to(dev) for _ in range(2)]   # time_offset 0.5
+        self.corr = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(B, h, w, gen)] for _ in range(2)]
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)      # noqa: E731
-        self.count, self.proj, self.out = e(1, 1, h, w), e(1, 2, h, w), [e(1, 3, h, w) for _ in range(2)]
+        self.count, self.proj, self.out = e(B, 1, h, w), e(B, 2, h, w), [e(B, 3, h, w) for _ in range(2)]
 
 
 def hip_timed(torch, dev, fn, iters, nsets=1, warm=3):
@@ -179,10 +181,14 @@ def run_stub(args, runner, rank, world):
 def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
     n_pairs = 64
     mine = list(runner.shard_pairs(n_pairs, rank, world))
-    pairs = [VimeoPair(torch, S, dev, S.SEED + 1000 + i) for i in mine]
+    # the rank's triplets go through in batches of at most three: PWC-Net's pre-built warp grid holds B_MAX = 3
+    # (PWCNet/PWCNet.py:144, 178; SURVEY.md 8d "cfg4 ... run as 8 x B=1 or B<=3 batches"); --vimeo-batch 1 = one by one
+    bmax = max(1, min(3, args.vimeo_batch))
+    sizes = [min(bmax, len(mine) - k) for k in range(0, len(mine), bmax)]
+    pairs = [VimeoPair(torch, S, dev, S.SEED + 1000 + mine[sum(sizes[:j])], batch=sizes[j]) for j in range(len(sizes))]
 
     def step(_i):
-        for p in pairs:                                     # B = 1 per call (PWC-Net's warp allows B <= 3, PWCNet.py:144)
+        for p in pairs:
             for d in range(2):
                 for a, b in p.corr[d]:
                     cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
@@ -192,7 +198,7 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
 
     for i in range(max(1, args.warmup)):
         step(i)
-    # 896 short launches per step (14 per pair): the host's ctypes calls, not the GPU, would set the pace.  The step is
+    # Hundreds of short launches per step (14 per batch): the host's ctypes calls, not the GPU, would set the pace.  The step is
     # captured once into a HIP graph (every entry point is capturable: no host synchronisation, workspaces already sized
     # by the warm-up) and replayed; --no-graph times the eager calls.
     launch, run = "eager calls", step
@@ -222,9 +228,9 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "vimeo64: 64 triplets 256x448 padded to %dx%d, DAIN x2 hot path per pair (10 correlation + "
-                               "2 FlowProjection(fillhole) + 2 FilterInterpolation(C=3)), B=1 per call; 1 frame per pair"
-                               % (h, w),
-                   "pairs": n_pairs, "pairs_per_rank": [len(runner.shard_pairs(n_pairs, r, world)) for r in range(world)],
+                               "2 FlowProjection(fillhole) + 2 FilterInterpolation(C=3)), B<=%d per call; 1 frame per pair"
+                               % (h, w, bmax),
+                   "pairs": n_pairs, "batches_per_rank_0": sizes, "pairs_per_rank": [len(runner.shard_pairs(n_pairs, r, world)) for r in range(world)],
                    "filter_size": 4, "launch": launch, "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
     }
 
