@@ -281,6 +281,14 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
                 b["loop"] = b["label"]
         is_dma = lambda i: i.startswith("buffer_load") and " lds" in i      # noqa: E731
         dma_loops = {b["loop"] for b in blocks if b["loop"] and any(is_dma(i) for i in b["ins"])}
+        # a loop whose every vmcnt wait is vmcnt(0) keeps nothing in flight across its waits (the two-slot rings of the
+        # largest windows): a reload cannot make those waits any stricter
+        counted = set()
+        for b in blocks:
+            for i in b["ins"]:
+                m = re.match(r"s_waitcnt vmcnt\((\d+)\)", i)
+                if m and int(m.group(1)) > 0 and b["loop"]:
+                    counted.add(b["loop"])
         for b in blocks:
             # (the multi-flow kernel keeps 2 x 3 pixel states: its straight-line prologue, which also issues the first
             #  windows, spills a few registers once per tile; what must stay clean there is the channel loop)
@@ -288,7 +296,7 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
             if "fi_forward_ori_ldsILb1E" in b["func"]:
                 continue            # the blend-epilogue instance runs 3-channel frames only: its ring is never deeper than that
             pipelined = (any(is_dma(i) for i in b["ins"]) and not prologue_ok) or (b["loop"] in dma_loops)
-            if not pipelined:
+            if not pipelined or (b["loop"] in dma_loops and b["loop"] not in counted and name == "filterinterp_multi.s"):
                 continue
             checked += 1
             spills = [i for i in b["ins"] if i.startswith("scratch_")]

@@ -17,6 +17,8 @@
 
 #include <limits.h>
 
+#include <type_traits>
+
 namespace vfi {
 
 #define FM_TW 64
@@ -33,6 +35,15 @@ namespace vfi {
 
 typedef __attribute__((address_space(3))) void* fm_lptr_t;
 
+// compile-time loop: the body sees a constant index (register arrays indexed by it stay in registers)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct FmPtrs { const float* flow[FM_MAXT]; float* out[FM_MAXT]; };
 struct FmWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
 template <int NT> struct FmPixel {
@@ -48,17 +59,29 @@ template <int K>
 __device__ __forceinline__ void fm_wait_windows(int younger_groups) {
     switch (younger_groups) {
     case 0:  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
-    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K) : "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K) : "memory"); break;
+    case 1:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K < 63 ? K : 63) : "memory"); break;
+    case 2:  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K < 63 ? 2 * K : 63) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * K < 63 ? 3 * K : 63) : "memory"); break;
     }
 }
 
+// Channel loop of one workgroup, written like fi_run_channels_lean (filterinterp_lds.hip: what bounds these loops is the
+// instruction count): ring geometry a compile-time function of K and one constant s_waitcnt in the steady state, running
+// plane pointers, M0 formed on the scalar unit, tap reads as asm (columns (0, 2) / (1, 3) of a row, so that one packed
+// multiply-add advances the left and the right quadrant sum) with one lgkmcnt wait per evaluation and the next evaluation's
+// first rows in flight under the current one's arithmetic, range-checked buffer stores.  An evaluation = one pixel under
+// one flow: 2 x NT per thread and channel.
 template <int K, int NT>
 __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
                                                 int c_begin, int c_end, int tid, const FmWindow& win,
-                                                const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring, int R) {
-    static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
+                                                const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr int NP = K * FM_THREADS;
+    constexpr int R = (FM_RING_FLOATS / NP) < FM_RMAX ? (FM_RING_FLOATS / NP) : FM_RMAX;
+    constexpr int D = R - 1;
+    constexpr int NE = FM_PX * NT;                           // evaluations per thread and channel, e = t * FM_PX + p
+    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    if (c_begin >= c_end) return;
     // staged element e = tid + k * FM_THREADS, row pitch a multiple of the 32 LDS banks, borders replicated while
     // staging, pad elements out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
     unsigned goff[K];
@@ -71,53 +94,118 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
     }
     const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
-    constexpr int NP = K * FM_THREADS;
-    const int D = R - 1;
-    auto issue = [&](int c, int slot) {
-        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
-        float* l = ring + slot * NP + tid;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(fm_lptr_t)ring;
+    const unsigned pitch4 = 4u * (unsigned)win.pitch;
+    unsigned lb[NE], soff[NE];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < FM_PX; ++p) {
+            lb[t * FM_PX + p] = ring_lds + 4u * (unsigned)px[p].lbase[t];       // (an invalid evaluation's reads land anywhere: discarded)
+            soff[t * FM_PX + p] = px[p].valid[t] ? 4u * px[p].pix : 0x80000000u;   // (its store is dropped by the range check)
+        }
+    // filter taps as (left quadrant, right quadrant) pairs: rows 0-1 feed the top sums, rows 2-3 the bottom ones (two flows;
+    // with three, 16 more aligned register pairs are more than the allocator places without spilling inside the loop)
+    constexpr bool PACKED = NT < 3;
+    v2f F[FM_PX][8];
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int p = 0; p < FM_PX; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                F[p][2 * r] = v2f{px[p].f[4 * r], px[p].f[4 * r + 2]};
+                F[p][2 * r + 1] = v2f{px[p].f[4 * r + 1], px[p].f[4 * r + 3]};
+            }
+    }
+    const int last = c_end - 1;
+    const float* pdma = img + (int64_t)c_begin * cs;
+    int64_t oofs = boff + (int64_t)c_begin * cs;            // element offset of the output plane inside every output tensor
+    auto issue = [&](int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
+        float* l = ring + slot * NP + wave_first;
 #pragma unroll
         for (int k = 0; k < K; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fm_lptr_t)(l + k * FM_THREADS), 4, goff[k], 0, 0, 0);
+        pdma += cs;
     };
-    auto compute = [&](int c, int slot) {
-        const float* base = ring + slot * NP;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            // a wave-uniform descriptor of output plane (t, c) + the pixel's 32-bit byte offset: no 64-bit vector
-            // addresses (2 x NT of them, kept across the channel loop, do not fit the 128 registers)
-            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + boff + (int64_t)c * cs), 0, plane_bytes, 0x00020000);
-#pragma unroll
-            for (int p = 0; p < FM_PX; ++p) {
-                if (px[p].valid[t]) {
-                    const float* tp = base + px[p].lbase[t];
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[r * 4 + k] = tp[r * win.pitch + k];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fi4_pixel(v, px[p].f, px[p].alpha[t], px[p].beta[t])), oplane,
-                                                          (int)(px[p].pix * 4u), 0, 0);
-                }
-                // one pixel evaluation at a time: left to itself the scheduler hoists the LDS reads of all 2 x NT
-                // evaluations (16 registers each) above the arithmetic and spills inside the counted-vmcnt loop
-                __builtin_amdgcn_sched_barrier(0);
+#define FM_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
+    auto compute = [&](int slot) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        // (a second evaluation in flight costs 16 registers: with three flows the allocator keeps it without spilling inside
+        //  the loop for one ring geometry only -- measured 2.91 against 2.97 ms per C=196 launch where it does)
+        constexpr bool OVERLAP = NT < 3 ? K <= 12 : K == 5;
+        v2f q[OVERLAP ? 2 : 1][8];
+        auto reads = [&](auto E, auto H) {                   // rows 2h, 2h + 1 of evaluation e
+            constexpr int e = decltype(E)::value, h = decltype(H)::value;
+            v2f (&d)[8] = q[OVERLAP ? (e & 1) : 0];
+            unsigned a = lb[e] + so + (h ? 2u * pitch4 : 0u);
+            FM_READ2(d[4 * h], a, 0, 2); FM_READ2(d[4 * h + 1], a, 1, 3);
+            a += pitch4;
+            FM_READ2(d[4 * h + 2], a, 0, 2); FM_READ2(d[4 * h + 3], a, 1, 3);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        reads(I0{}, I0{}); reads(I0{}, I1{});
+        if constexpr (OVERLAP) reads(I1{}, I0{});
+        static_for<0, NE>([&](auto E) {
+            constexpr int e = decltype(E)::value, t = e / FM_PX, p = e % FM_PX;
+            v2f (&d)[8] = q[OVERLAP ? (e & 1) : 0];
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                    "+v"(d[6]), "+v"(d[7]) : "n"(OVERLAP && e + 1 < NE ? 4 : 0));
+            v2f top, bot;
+            if constexpr (PACKED) {
+                top = d[0] * F[p][0];                       // (same order per quadrant sum as fi4_pixel)
+                top = __builtin_elementwise_fma(d[1], F[p][1], top);
+                top = __builtin_elementwise_fma(d[2], F[p][2], top);
+                top = __builtin_elementwise_fma(d[3], F[p][3], top);
+                bot = d[4] * F[p][4];
+                bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
+                bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
+                bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
+            } else {
+                // d[2r] = columns (0, 2), d[2r + 1] = columns (1, 3) of row r; the sums of fi4_pixel, one float at a time
+                const float (&f)[16] = px[p].f;
+                float TL = d[0].x * f[0];  TL = fmaf(d[1].x, f[1], TL);  TL = fmaf(d[2].x, f[4], TL);   TL = fmaf(d[3].x, f[5], TL);
+                float TR = d[0].y * f[2];  TR = fmaf(d[1].y, f[3], TR);  TR = fmaf(d[2].y, f[6], TR);   TR = fmaf(d[3].y, f[7], TR);
+                float BL = d[4].x * f[8];  BL = fmaf(d[5].x, f[9], BL);  BL = fmaf(d[6].x, f[12], BL);  BL = fmaf(d[7].x, f[13], BL);
+                float BR = d[4].y * f[10]; BR = fmaf(d[5].y, f[11], BR); BR = fmaf(d[6].y, f[14], BR);  BR = fmaf(d[7].y, f[15], BR);
+                top = v2f{TL, TR}; bot = v2f{BL, BR};
             }
-        }
+            // (the four blend weights are formed here each time: kept across the loop for 2 x NT evaluations they do not fit)
+            float al = px[p].alpha[t], be = px[p].beta[t];
+            asm volatile("" : "+v"(al), "+v"(be));
+            const float val = blend4(al, be, top.x, top.y, bot.x, bot.y);
+            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[e], 0, 0);
+            if constexpr (OVERLAP) {
+                if constexpr (e + 1 < NE) reads(std::integral_constant<int, e + 1>{}, I1{});
+                if constexpr (e + 2 < NE) reads(std::integral_constant<int, e + 2>{}, I0{});
+            } else if constexpr (e + 1 < NE) {
+                reads(std::integral_constant<int, e + 1>{}, I0{}); reads(std::integral_constant<int, e + 1>{}, I1{});
+            }
+        });
+        oofs += cs;
     };
-
-    if (c_begin >= c_end) return;
-    const int last = c_end - 1;
-    for (int j = 0; j < D; ++j)
-        if (c_begin + j <= last) issue(c_begin + j, j);
-    fm_wait_windows<K>(min(c_begin + D - 1, last) - c_begin);
-    __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int c = c_begin; c <= last; ++c) {
-        if (c + D <= last) issue(c + D, slot == 0 ? R - 1 : slot - 1);
-        compute(c, slot);
-        if (c < last) fm_wait_windows<K>(min(c + D, last) - (c + 1));
+#undef FM_READ2
+    const int n0 = min(D, c_end - c_begin);
+    for (int j = 0; j < n0; ++j) issue(j);
+    fm_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
+    __builtin_amdgcn_s_barrier();                               // ... in every wave
+    int c = c_begin, slot = 0;
+    for (; c + D <= last; ++c) {                                // steady state: window c + D exists
+        issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        compute(slot);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
         __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
+        compute(slot);
+        if (c < last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
     // copy-through of the invalid pixels (:2814-2818), outside the pipelined loop
@@ -126,8 +214,8 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
 #pragma unroll
         for (int p = 0; p < FM_PX; ++p)
             if (px[p].inimg && !px[p].valid[t])
-                for (int c = c_begin; c < c_end; ++c)
-                    ptr.out[t][boff + (int64_t)c * cs + px[p].pix] = img[(int64_t)c * cs + px[p].pix];
+                for (int cc = c_begin; cc < c_end; ++cc)
+                    ptr.out[t][boff + (int64_t)cc * cs + px[p].pix] = img[(int64_t)cc * cs + px[p].pix];
 }
 
 template <int NT>
@@ -247,8 +335,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
 
     const FmWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FM_HDR;
-#define FM_RUN(K) fm_run_channels<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring, \
-                                         min(FM_RMAX, FM_RING_FLOATS / ((K) * FM_THREADS)))
+#define FM_RUN(K) fm_run_channels<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
     if (kmax <= 2) FM_RUN(2);
     else if (kmax == 3) FM_RUN(3);
     else if (kmax == 4) FM_RUN(4);
