@@ -21,8 +21,8 @@ out = torch.empty_like(ctx[0])
 depth = S.depth_weight(1, h, w, gen).to(dev)
 count = torch.zeros((1, 1, h, w), device=dev); proj = torch.zeros((1, 2, h, w), device=dev)
 knob = cabi.lib().vfi_dev_filterinterp
-def iso(groups, n=40):
-    knob(8, groups)
+def iso(groups, n=40, flags=8):
+    knob(flags, groups)
     ts = []
     for i in range(n + 5):
         cabi.depthflowprojection_forward(flow, depth, count, proj, 1)          # something short in front, as in the step
@@ -32,6 +32,10 @@ def iso(groups, n=40):
         if i >= 5: ts.append(e0.elapsed_time(e1))
     ts.sort()
     return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+import sys as _sys
+FLAGS = [int(v, 0) for v in _sys.argv[1].split(",")] if len(_sys.argv) > 1 else [8]
+GROUPS = [int(v) for v in _sys.argv[2].split(",")] if len(_sys.argv) > 2 else [1, 2, 3, 4, 6, 8]
 for rep in range(2):
-    for g in (1, 2, 3, 4, 6, 8):
-        print("groups knob %d: mean %.4f median %.4f min %.4f ms" % ((g,) + iso(g)), flush=True)
+    for fl in FLAGS:
+        for g in GROUPS:
+            print("flags %#x groups knob %d: mean %.4f median %.4f min %.4f ms" % ((fl, g) + iso(g, flags=fl)), flush=True)
