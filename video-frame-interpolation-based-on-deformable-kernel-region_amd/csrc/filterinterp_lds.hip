@@ -362,14 +362,67 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         });
         pout += cs;
     };
-#undef FI_READ2
-#undef FI_READ64
+    // Two pixels, 4-byte reads: the pipeline is skewed by one pixel across the barrier.  In channel c a wave issues pixel 0's
+    // reads, multiplies pixel 1 of channel c - 1 (its taps were read before the barrier and wait in registers), issues pixel
+    // 1's reads, multiplies pixel 0, and waits for pixel 1's taps: every LDS read is in flight under arithmetic of the same
+    // wave, none is waited for with nothing to do (the plain order exposes the first reads after each barrier).
+    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 10 * FI_KS;     // (the two largest ring geometries have no registers to spare)
+    v2f qa[8], qb[8];
+    auto rd_all = [&](v2f (&d)[8], int p, unsigned so) {
+        unsigned a = lb[p] + so;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { FI_READ2(d[2 * r], a, 0, 2); FI_READ2(d[2 * r + 1], a, 1, 3); a += pitch4; }
+    };
+    auto fma_store = [&](const v2f (&d)[8], int p, const float* plane_ptr) {
+        v2f top = d[0] * F[p][0];                           // (same order per quadrant sum as fi4_pixel)
+        top = __builtin_elementwise_fma(d[1], F[p][1], top);
+        top = __builtin_elementwise_fma(d[2], F[p][2], top);
+        top = __builtin_elementwise_fma(d[3], F[p][3], top);
+        v2f bot = d[4] * F[p][4];
+        bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
+        bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
+        bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
+        const float val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)plane_ptr, 0, plane_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+    };
+    auto compute_skewed = [&](int slot, bool first) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        rd_all(qa, 0, so);
+        if (!first) fma_store(qb, 1, pout - cs);            // pixel 1 of the previous channel
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");  // (at most 15 LDS reads outstanding)
+        rd_all(qb, 1, so);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(qa[4]), "+v"(qa[5]), "+v"(qa[6]), "+v"(qa[7]));
+        fma_store(qa, 0, pout);
+        // pixel 1's taps are in registers before the barrier: the slot may be overwritten after it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]), "+v"(qb[4]), "+v"(qb[5]), "+v"(qb[6]), "+v"(qb[7]));
+        pout += cs;
+    };
+    const bool skew = SKEW && !(abl & 32);
     // prologue: the first D windows
     const int n0 = min(D, c_end - c_begin);
     for (int j = 0; j < n0; ++j) issue(j);
     fi_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
     int c = c_begin, slot = 0;
+    if constexpr (SKEW) if (skew) {
+        for (; c + D <= last; ++c) {
+            issue(slot == 0 ? R - 1 : slot - 1);
+            compute_skewed(slot, c == c_begin);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1 == R) ? 0 : slot + 1;
+        }
+        for (; c <= last; ++c) {
+            compute_skewed(slot, c == c_begin);
+            if (c < last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            slot = (slot + 1 == R) ? 0 : slot + 1;
+        }
+        fma_store(qb, 1, pout - cs);                            // pixel 1 of the last channel
+    }
     for (; c + D <= last; ++c) {                                // steady state: window c + D exists
         issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
         compute(slot);
@@ -385,6 +438,8 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+#undef FI_READ2
+#undef FI_READ64
 #pragma unroll
     for (int p = 0; p < FI_PX; ++p)                             // copy-through of the (rare) invalid pixels (:2814-2818)
         if (px[p].inimg && !px[p].valid)
