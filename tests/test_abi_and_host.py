@@ -296,7 +296,7 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
             if "fi_forward_ori_ldsILb1E" in b["func"]:
                 continue            # the blend-epilogue instance runs 3-channel frames only: its ring is never deeper than that
             pipelined = (any(is_dma(i) for i in b["ins"]) and not prologue_ok) or (b["loop"] in dma_loops)
-            if not pipelined or (b["loop"] in dma_loops and b["loop"] not in counted and name == "filterinterp_multi.s"):
+            if not pipelined or (b["loop"] in dma_loops and b["loop"] not in counted):
                 continue
             checked += 1
             spills = [i for i in b["ins"] if i.startswith("scratch_")]

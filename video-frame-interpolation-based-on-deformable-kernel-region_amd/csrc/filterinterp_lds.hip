@@ -366,23 +366,51 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     // reads, multiplies pixel 1 of channel c - 1 (its taps were read before the barrier and wait in registers), issues pixel
     // 1's reads, multiplies pixel 0, and waits for pixel 1's taps: every LDS read is in flight under arithmetic of the same
     // wave, none is waited for with nothing to do (the plain order exposes the first reads after each barrier).
-    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 10 * FI_KS;     // (the two largest ring geometries have no registers to spare)
-    v2f qa[8], qb[8];
-    auto rd_all = [&](v2f (&d)[8], int p, unsigned so) {
+    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 10 * FI_KS;     // (4-byte reads; with 8-byte reads -- 24 more registers in flight -- it measured 30 % slower; the two largest ring geometries have no registers to spare)
+    constexpr int NQS = B64 ? 12 : 8;                        // register pairs per pixel
+    v2f qa[NQS], qb[NQS];
+    auto rd_all = [&](v2f (&d)[NQS], int p, unsigned so) {
         unsigned a = lb[p] + so;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { FI_READ2(d[2 * r], a, 0, 2); FI_READ2(d[2 * r + 1], a, 1, 3); a += pitch4; }
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (B64) { FI_READ64(d[3 * r], a, 0); FI_READ64(d[3 * r + 1], a, 8); FI_READ64(d[3 * r + 2], a, 16); }
+            else { FI_READ2(d[2 * r], a, 0, 2); FI_READ2(d[2 * r + 1], a, 1, 3); }
+            a += pitch4;
+        }
     };
-    auto fma_store = [&](const v2f (&d)[8], int p, const float* plane_ptr) {
-        v2f top = d[0] * F[p][0];                           // (same order per quadrant sum as fi4_pixel)
-        top = __builtin_elementwise_fma(d[1], F[p][1], top);
-        top = __builtin_elementwise_fma(d[2], F[p][2], top);
-        top = __builtin_elementwise_fma(d[3], F[p][3], top);
-        v2f bot = d[4] * F[p][4];
-        bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
-        bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
-        bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
-        const float val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+    auto arrived_s = [&](v2f (&d)[NQS], auto LATER) {       // waits until all but the `later` youngest LDS reads are back
+        constexpr int later = decltype(LATER)::value;
+        if constexpr (B64)
+            asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                     "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]) : "n"(later));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                    "+v"(d[6]), "+v"(d[7]) : "n"(later));
+    };
+    auto fma_store = [&](const v2f (&d)[NQS], int p, const float* plane_ptr) {
+        float val;
+        if constexpr (B64) {
+            const bool odd = px[p].odd;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r * 4 + 0] = odd ? d[3 * r].y : d[3 * r].x;
+                v[r * 4 + 1] = odd ? d[3 * r + 1].x : d[3 * r].y;
+                v[r * 4 + 2] = odd ? d[3 * r + 1].y : d[3 * r + 1].x;
+                v[r * 4 + 3] = odd ? d[3 * r + 2].x : d[3 * r + 1].y;
+            }
+            val = fi4_pixel(v, px[p].f, px[p].alpha, px[p].beta);
+        } else {
+            v2f top = d[0] * F[p][0];                       // (same order per quadrant sum as fi4_pixel)
+            top = __builtin_elementwise_fma(d[1], F[p][1], top);
+            top = __builtin_elementwise_fma(d[2], F[p][2], top);
+            top = __builtin_elementwise_fma(d[3], F[p][3], top);
+            v2f bot = d[4] * F[p][4];
+            bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
+            bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
+            bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
+            val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
+        }
         const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)plane_ptr, 0, plane_bytes, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
     };
@@ -390,12 +418,13 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         const unsigned so = (unsigned)(slot * (NP * 4));
         rd_all(qa, 0, so);
         if (!first) fma_store(qb, 1, pout - cs);            // pixel 1 of the previous channel
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");  // (at most 15 LDS reads outstanding)
+        // (at most 15 LDS reads outstanding)
+        if constexpr (B64) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
         rd_all(qb, 1, so);
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(qa[4]), "+v"(qa[5]), "+v"(qa[6]), "+v"(qa[7]));
+        arrived_s(qa, std::integral_constant<int, NQS>{});
         fma_store(qa, 0, pout);
         // pixel 1's taps are in registers before the barrier: the slot may be overwritten after it
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]), "+v"(qb[4]), "+v"(qb[5]), "+v"(qb[6]), "+v"(qb[7]));
+        arrived_s(qb, std::integral_constant<int, 0>{});
         pout += cs;
     };
     const bool skew = SKEW && !(abl & 32);
