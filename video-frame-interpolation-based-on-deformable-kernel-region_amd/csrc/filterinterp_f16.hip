@@ -169,39 +169,43 @@ __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img,
     };
 #define F16_READ2(dst, addr) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(dst) : "v"(addr))
 #define F16_READ1(dst, addr) asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(dst) : "v"(addr))
-    auto compute = [&](int slot) {
-        const unsigned so = (unsigned)(slot * (NP * 4));
-        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, plane_bytes, 0x00020000);
-        v2u a01[2][4];          // dwords 0, 1 of the four tap rows, two pixels
-        unsigned a2[2][4];      // dword 2
-        auto reads = [&](int p, int r0) {                   // rows r0, r0 + 1 of pixel p
-            unsigned a = lb[p] + so + (r0 ? 2u * pitch4 : 0u);
-            F16_READ2(a01[p][r0], a); F16_READ1(a2[p][r0], a);
-            a += pitch4;
-            F16_READ2(a01[p][r0 + 1], a); F16_READ1(a2[p][r0 + 1], a);
-        };
-        auto pixel = [&](int p) {
-            float acc = 0.0f;
+    // The pipeline is skewed by one pixel across the barrier (filterinterp_lds.hip): in channel c a wave issues pixel 0's
+    // reads, does the arithmetic of pixel 1 of channel c - 1 (taps read before the barrier, waiting in registers), issues
+    // pixel 1's reads, does pixel 0, and waits for pixel 1's taps -- every LDS read is in flight under the wave's own arithmetic.
+    v2u a01[2][4];          // dwords 0, 1 of the four tap rows, two pixels
+    unsigned a2[2][4];      // dword 2
+    auto reads = [&](int p, unsigned so) {
+        unsigned a = lb[p] + so;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // ({d1,d0} >> sh) and ({d2,d1} >> sh): the four taps as two packed pairs
-                const unsigned e0 = __builtin_amdgcn_alignbit(a01[p][r].y, a01[p][r].x, sh[p]);
-                const unsigned e1 = __builtin_amdgcn_alignbit(a2[p][r], a01[p][r].y, sh[p]);
-                acc = fmaf(f16_lo(e0), px[p].g[r * 4 + 0], acc);
-                acc = fmaf(f16_hi(e0), px[p].g[r * 4 + 1], acc);
-                acc = fmaf(f16_lo(e1), px[p].g[r * 4 + 2], acc);
-                acc = fmaf(f16_hi(e1), px[p].g[r * 4 + 3], acc);
-            }
-            __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f16_store_value(acc)), oplane, soff[p], 0, 0);
-        };
-        reads(0, 0); reads(0, 2); reads(1, 0);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a01[0][0]), "+v"(a01[0][1]), "+v"(a01[0][2]), "+v"(a01[0][3]),
+        for (int r = 0; r < 4; ++r) { F16_READ2(a01[p][r], a); F16_READ1(a2[p][r], a); a += pitch4; }
+    };
+    auto pixel = [&](int p, const __half* plane_ptr) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // ({d1,d0} >> sh) and ({d2,d1} >> sh): the four taps as two packed pairs
+            const unsigned e0 = __builtin_amdgcn_alignbit(a01[p][r].y, a01[p][r].x, sh[p]);
+            const unsigned e1 = __builtin_amdgcn_alignbit(a2[p][r], a01[p][r].y, sh[p]);
+            acc = fmaf(f16_lo(e0), px[p].g[r * 4 + 0], acc);
+            acc = fmaf(f16_hi(e0), px[p].g[r * 4 + 1], acc);
+            acc = fmaf(f16_lo(e1), px[p].g[r * 4 + 2], acc);
+            acc = fmaf(f16_hi(e1), px[p].g[r * 4 + 3], acc);
+        }
+        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)plane_ptr, 0, plane_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f16_store_value(acc)), oplane, soff[p], 0, 0);
+    };
+    auto compute = [&](int slot, bool first) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        reads(0, so);
+        if (!first) pixel(1, pout - cs);                    // pixel 1 of the previous channel
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");  // (at most 15 LDS reads outstanding)
+        reads(1, so);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a01[0][0]), "+v"(a01[0][1]), "+v"(a01[0][2]), "+v"(a01[0][3]),
                                                "+v"(a2[0][0]), "+v"(a2[0][1]), "+v"(a2[0][2]), "+v"(a2[0][3]));
-        pixel(0);
-        reads(1, 2);
+        pixel(0, pout);
+        // pixel 1's taps are in registers before the barrier: the slot may be overwritten after it
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01[1][0]), "+v"(a01[1][1]), "+v"(a01[1][2]), "+v"(a01[1][3]),
                                                "+v"(a2[1][0]), "+v"(a2[1][1]), "+v"(a2[1][2]), "+v"(a2[1][3]));
-        pixel(1);
         pout += cs;
     };
 #undef F16_READ2
@@ -213,19 +217,20 @@ __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img,
     int c = c_begin, slot = 0;
     for (; c + D <= last; ++c) {                                // steady state: window c + D exists
         issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
-        compute(slot);
+        compute(slot, c == c_begin);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
         __builtin_amdgcn_s_barrier();
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
     for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
-        compute(slot);
+        compute(slot, c == c_begin);
         if (c < last) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+    pixel(1, pout - cs);                                        // pixel 1 of the last channel
 #pragma unroll
     for (int p = 0; p < F16_PX; ++p)
         if (px[p].inimg && !px[p].valid)
