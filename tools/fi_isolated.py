@@ -9,7 +9,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 import torch
 import vfidkr_amd
-vfidkr_amd.LIB_PATH = os.path.join(ROOT, "video-frame-interpolation-based-on-deformable-kernel-region_amd", "lib_dev", "libvfi_hip.so")
+vfidkr_amd.LIB_PATH = os.path.join(ROOT, "video-frame-interpolation-based-on-deformable-kernel-region_amd", os.environ.get("FI_LIBDIR", "lib_dev"), "libvfi_hip.so")
 from vfidkr_amd import cabi, synthetic as S
 dev = torch.device("cuda:0")
 h, w = S.padded_size(1080, 1920)
