@@ -136,11 +136,12 @@ __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img,
     // dword e = tid + k*F16_THREADS of the staged window, row-major, `pitch` dwords per row; rows
     // clamped to the image, columns never out of it; pad dwords get an out-of-range offset (the
     // load returns 0 without touching memory)
+    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int e = tid + k * F16_THREADS;
-        const int r = e / win.pitch;
+        const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
         const unsigned off = 2u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + win.bx0 + 2 * col);
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;

@@ -123,11 +123,12 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
     // channel from scalars) + one 32-bit byte offset per element that never changes -- no
     // per-channel vector address arithmetic, one VGPR per element.  One buffer_load_dword ... lds
     // writes 64 consecutive floats: LDS destination = wave-uniform base + lane*4 = this layout.
+    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int e = tid + k * FI_THREADS;
-        const int r = e / win.pitch;
+        const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
         const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
@@ -232,11 +233,12 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     constexpr int D = R - 1;
     static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
     if (c_begin >= c_end) return;
+    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int e = tid + k * FI_THREADS;
-        const int r = e / win.pitch;
+        const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
         const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;

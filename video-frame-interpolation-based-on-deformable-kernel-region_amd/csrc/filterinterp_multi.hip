@@ -84,11 +84,12 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
     if (c_begin >= c_end) return;
     // staged element e = tid + k * FM_THREADS, row pitch a multiple of the 32 LDS banks, borders replicated while
     // staging, pad elements out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
+    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int e = tid + k * FM_THREADS;
-        const int r = e / win.pitch;
+        const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
         const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
