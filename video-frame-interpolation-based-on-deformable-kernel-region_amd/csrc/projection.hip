@@ -65,7 +65,7 @@ namespace vfi {
 #define PROJ_BLK 16                 // source block edge
 #define PROJ_ADD_BITS 25            // |scaled addend| < 2^25
 #define PROJ_ADD_CELL 32            // addends per cell that fit beside it in 32 bits
-#define PROJ_CLS_BITS 12            // binary orders of magnitude of weight per accumulation pass (DepthFlowProjection)
+#define PROJ_CLS_BITS 6             // binary orders of magnitude of weight per accumulation pass (DepthFlowProjection)
 #define PROJ_BLOCK_CAP 64           // output tiles one block may reach before the call takes the fallback
 
 // workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     // DepthFlowProjection: the weights (inverse depth, 1e-6 + exp(-d): DAIN_slowmotion.py:143) can span many
     // orders of magnitude inside one tile, e.g. at the edge of a near object in front of sky, and a cell that only
     // far-away sources reach must still get full relative precision (the reference's fp32 sums give it that).  So
-    // the sources are taken in up to four passes by weight class -- class j: weights within 2^(-12 j) .. 2^(-12 j - 12)
+    // the sources are taken in up to four passes by weight class -- class j: weights within 2^(-6 j) .. 2^(-6 j - 6)
     // of the largest, the last class everything below -- each pass with its own scale, exact integer sums, one
     // rounding to float, and the classes' results are added.  Almost every tile has one class.
     int ef = 0, ec = 0;
