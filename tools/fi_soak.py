@@ -61,6 +61,23 @@ for it in range(cases):
     for f, o in zip(flows, outs):
         assert cabi.filterinterp_forward_ori(img, f, filt, ref, direct=True) == 0
         ok = ok and same(o, ref)
+    # other filter sizes (staged fs = 2, 5, 6 against the direct kernel) and the three deformable variants (staged against
+    # the general kernel), on a dense copy, every few cases
+    if it % 3 == 0 and H * W <= 120000:
+        imgd = img.contiguous()
+        for fs in (2, 5, 6):
+            fl = torch.rand(B, fs * fs, H, W, generator=gen).to(dev)
+            a, b_ = torch.full_like(imgd, float("nan")), torch.empty_like(imgd)
+            assert cabi.filterinterp_forward_ori(imgd, flow, fl, a) == 0
+            assert cabi.filterinterp_forward_ori(imgd, flow, fl, b_, direct=True) == 0
+            ok = ok and same(a, b_)
+        off = (torch.randn(B, 32, H, W, generator=gen) * float(rng.choice([0.3, 1.5, 6.0]))).to(dev)
+        for variant in (0, 1, 2):
+            a, b_ = torch.full_like(imgd, float("nan")), torch.empty_like(imgd)
+            i3, i4 = (off, None) if variant == 2 else (filt, off)
+            assert cabi.filterinterp_forward_defor(variant, imgd, flow, i3, i4, a) == 0
+            assert cabi.filterinterp_forward_defor(variant, imgd, flow, i3, i4, b_, general=True) == 0
+            ok = ok and same(a, b_)
     if not ok:
         bad += 1
         print("MISMATCH case %d: B=%d C=%d H=%d W=%d %s" % (it, B, C, H, W, kind), flush=True)
