@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Soak of the other hot-path entry points against the CPU oracle on random shapes (larger and more varied than the
+hypothesis-drawn unit tests): correlation fp32 and half (every k = 1 kernel: flat, tiled, 16-byte rows), PWC-Net's warp
+alone and feeding the correlation in one launch, the x4-upsample fused into the projection, MinDepthFlowProjection,
+Interpolation, the FilterInterpolation backward (per-pixel gradients bit-exact, image gradient within GRAD_TOL).
+    python tests/soak_ops.py [cases] [seed]        (not collected by pytest; the oracle is the checker)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import vfidkr_amd  # noqa: E402,F401
+from vfidkr_amd import cabi  # noqa: E402
+from oracle import cpu_oracle as oracle  # noqa: E402  (test infrastructure: the checker)
+oracle.build()
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+f32 = np.float32
+dev = torch.device("cuda:0")
+gpu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+cpu = lambda t: t.detach().cpu().numpy()                               # noqa: E731
+bad = 0
+
+
+def check(name, ok, info=""):
+    global bad
+    if not ok:
+        bad += 1
+        print("MISMATCH %s %s" % (name, info), flush=True)
+
+
+for it in range(cases):
+    B = int(rng.choice([1, 1, 2]))
+    C = int(rng.choice([1, 3, 8, 19, 32, 67]))
+    H = int(rng.choice([1, 4, 9, 33, 64, 72, 130]))
+    W = int(rng.choice([1, 5, 16, 31, 64, 124, 248]))
+    info = "case %d B=%d C=%d H=%d W=%d" % (it, B, C, H, W)
+    f1 = rng.standard_normal((B, C, H, W)).astype(f32)
+    f2 = rng.standard_normal((B, C, H, W)).astype(f32)
+    g1, g2 = gpu(f1), gpu(f2)
+    # ---- correlation, PWC-Net's configuration
+    want = oracle.correlation_fwd(f1, f2, 4, 1, 4, 1, 1, order=1, fmad=1)
+    check("correlation fp32", np.array_equal(cpu(cabi.correlation_forward(g1, g2, 4, 1, 4, 1, 1)), want), info)
+    if C <= 32:
+        h1, h2 = f1.astype(np.float16), f2.astype(np.float16)
+        want16 = oracle.correlation_fwd_f16(h1, h2, 4, 1, 4, 1, 1)
+        got16 = cpu(cabi.correlation_forward(gpu(h1), gpu(h2), 4, 1, 4, 1, 1))
+        check("correlation half", np.array_equal(got16.view(np.uint16), want16.view(np.uint16)), info)
+    # ---- PWC warp, alone and fused into the correlation
+    flo = (rng.standard_normal((B, 2, H, W)) * float(rng.choice([0.3, 2.0, 9.0]))).astype(f32)
+    gfl = gpu(flo)
+    warped = torch.empty_like(g2)
+    assert cabi.pwc_warp_forward(g2, gfl, warped, True) == 0
+    w_ref = oracle.pwc_warp(f2, flo, True, fmad=1)
+    check("pwc_warp", np.array_equal(cpu(warped), w_ref), info)
+    fused = cabi.pwc_warp_correlation_forward(g1, g2, gfl, True)
+    check("warp + correlation, one launch", np.array_equal(cpu(fused), oracle.correlation_fwd(f1, w_ref, 4, 1, 4, 1, 1, order=1, fmad=1)), info)
+    # ---- projection from the quarter-resolution flow, MinDepth, Interpolation
+    hq, wq = max(1, H // 4), max(1, W // 4)
+    fq = (np.round(rng.standard_normal((B, 2, hq, wq)) * 4) / 4).astype(f32)          # dyadic: x 20 x 0.25 / 0.5 stay exact
+    for fh in (0, 1):
+        count = torch.full((B, 1, 4 * hq, 4 * wq), float("nan"), device=dev)
+        out = torch.full((B, 2, 4 * hq, 4 * wq), float("nan"), device=dev)
+        assert cabi.flowprojection_forward_up4(gpu(fq), count, out, 16.0, 0.5, fh) == 0
+        r, rc = oracle.flowproj_up4_fwd(fq, 16.0, 0.5, fh)
+        check("projection from quarter flow", np.array_equal(cpu(count), rc) and np.abs(cpu(out) - r).max() <= 1e-4, info + " fillhole=%d" % fh)
+    fd = (np.round(flo * 8) / 8).astype(f32)
+    wgt = (np.round(rng.uniform(0.1, 1.0, (B, 1, H, W)) * 16) / 16 + 1 / 16).astype(f32)
+    for fh in (0, 1):
+        count, out = torch.zeros((B, 1, H, W), device=dev), torch.zeros((B, 2, H, W), device=dev)
+        assert cabi.mindepthflowprojection_forward(gpu(fd), gpu(wgt), count, out, fh) == 0
+        r, rc = oracle.mindepthflowproj_fwd(fd, wgt, fh)
+        check("MinDepthFlowProjection", np.array_equal(cpu(count), rc) and np.array_equal(cpu(out), r), info + " fillhole=%d" % fh)
+    if C <= 8:
+        out = torch.full((B, C, H, W), float("nan"), device=dev)
+        assert cabi.interpolation_forward(g1, gfl, out) == 0
+        check("Interpolation", np.array_equal(cpu(out), oracle.interp_fwd(f1, flo, fmad=1)), info)
+        # ---- FilterInterpolation backward
+        filt = rng.random((B, 16, H, W), dtype=f32)
+        gout = rng.standard_normal((B, C, H, W)).astype(f32)
+        gi1, gi2, gi3 = (torch.zeros(s, device=dev) for s in ((B, C, H, W), (B, 2, H, W), (B, 16, H, W)))
+        assert cabi.filterinterp_backward_ori(g1, gfl, gpu(filt), gpu(gout), gi1, gi2, gi3) == 0
+        r1, r2, r3 = oracle.filterinterp_ori_bwd(f1, flo, filt, gout, fmad=1)
+        check("FilterInterpolation backward", np.array_equal(cpu(gi2), r2) and np.array_equal(cpu(gi3), r3)
+              and np.abs(cpu(gi1) - r1).max() <= 2e-6 * max(1.0, np.abs(r1).max()), info)
+    if it % 20 == 19:
+        print("%d cases, %d mismatches" % (it + 1, bad), flush=True)
+print("done: %d cases, %d mismatches" % (cases, bad))
+sys.exit(1 if bad else 0)
