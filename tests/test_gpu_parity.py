@@ -825,6 +825,27 @@ def test_correlation_half_1080p_tiled_equals_one_thread_per_output(torch_mod, ca
         assert torch.equal(tiled.view(torch.int16), plain.view(torch.int16))
 
 
+def test_projection_fallback_scratch_is_cleaned_across_frame_sizes(torch_mod, cabi, oracle):
+    """The atomic fallback (a field that scatters a block over more than 64 tiles) leaves sums in the workspace's scratch
+    planes, which the NEXT call cleans.  That call may be on a smaller frame: it has to clean what was dirtied, not what
+    it would dirty itself -- a large wild field, a small smooth one, a large wild one again, each against the oracle
+    (found by tests/soak_projection.py: the third call used to add onto the first one's leftovers)."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    big = (np.round(rng.uniform(-300, 300, (1, 2, 211, 700)) * 8) / 8).astype(f32)
+    small = (np.round(rng.uniform(-2, 2, (1, 2, 40, 130)) * 8) / 8).astype(f32)
+    big2 = (np.round(rng.uniform(-300, 300, (1, 2, 211, 700)) * 8) / 8).astype(f32)
+    for flow in (big, small, big2, small, big):
+        B, _, H, W = flow.shape
+        for fh in (0, 1):
+            count = torch.full((B, 1, H, W), float("nan"), device="cuda:0")
+            out = torch.full((B, 2, H, W), float("nan"), device="cuda:0")
+            assert cabi.flowprojection_forward(gpu(torch, flow), count, out, fh) == 0
+            r, rc = oracle.flowproj_fwd(flow, fh)
+            assert np.array_equal(cpu(count), rc)
+            assert np.abs(cpu(out) - r).max() <= 1e-4 * max(1.0, np.abs(r).max())
+
+
 def test_frame_ssim(torch_mod, cabi, oracle):
     """SSIM as demo_MiddleBury.py:382-388 reports it; float32 on the GPU against the float64 oracle."""
     torch = torch_mod

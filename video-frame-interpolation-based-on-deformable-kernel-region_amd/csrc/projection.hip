@@ -82,6 +82,12 @@ namespace vfi {
 #define PROJ_TILE_WORDS 8
 #define PROJ_INV_BITS 0x7f7fffff       // a weight's bits are stored as this minus them where the SMALLEST is wanted
 
+// header words [2], [3]: how many floats of the fallback's scratch planes hold sums (64 bits; 0 = clean).  The count, not a
+// flag: the next call cleans what THIS call dirtied, whatever its own frame size is.
+__device__ __forceinline__ int64_t proj_dirty_floats(const int* ws) {
+    return (int64_t)(unsigned)ws[PROJ_WS_DIRTY] | ((int64_t)(unsigned)ws[PROJ_WS_DIRTY + 1] << 32);
+}
+
 // rmw / cmw: 32-bit words per image row / column of the two bitmaps; rowmap / colmap: their word offsets
 // inside the bit buffer; off_tile / off_list: word offsets of the tile records and of the hole list
 struct ProjGeom {
@@ -265,11 +271,12 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
 template <bool DEPTH, bool UP>
 __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __restrict__ ws, float* __restrict__ planes,
                                                 int64_t plane_floats) {
-    if (ws[PROJ_WS_DIRTY] != 0) {
-        // the previous call on this workspace took the fallback: its scratch planes are cleaned here,
-        // a slice per workgroup (this call's K1 rewrites the word)
-        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
+    const int64_t dirty = proj_dirty_floats(ws);
+    if (dirty != 0) {
+        // the previous call on this workspace took the fallback: the floats IT dirtied (its frame may have been larger
+        // than this one) are cleaned here, a slice per workgroup (this call's K1 rewrites the words)
+        const int64_t chunk = (dirty + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(dirty, lo + chunk);
         for (int64_t i = lo + threadIdx.x; i < hi; i += 64) planes[i] = 0.0f;
     }
     const int tile = blockIdx.x, lane = threadIdx.x;
@@ -331,9 +338,10 @@ __device__ __forceinline__ int quad_max(int v) { PROJ_QUAD_STEP(max, 0xb1); PROJ
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int groups_x, int* __restrict__ ws,
                                                   float* __restrict__ planes, int64_t plane_floats) {
-    if (ws[PROJ_WS_DIRTY] != 0) {
-        const int64_t chunk = (plane_floats + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(plane_floats, lo + chunk);
+    const int64_t dirty = proj_dirty_floats(ws);
+    if (dirty != 0) {                                       // (see proj_scan)
+        const int64_t chunk = (dirty + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(dirty, lo + chunk);
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
     }
     __shared__ int sblk[16][7];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits
@@ -470,7 +478,7 @@ __device__ __forceinline__ void pull_add(unsigned long long* accv, typename Proj
 template <bool DEPTH, bool UP, bool VEC>
 __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
-    int64_t cb, int ch, int vec_ok, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes) {
+    int64_t cb, int ch, int vec_ok, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats) {
     typedef typename ProjCountCell<DEPTH>::type ccell;
     __shared__ uint4 lds[ProjLds<DEPTH>::total / 16];
     unsigned long long* accv = reinterpret_cast<unsigned long long*>(lds);
@@ -490,7 +498,10 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_t1 = 0, st_t2 = 0;
 #endif
-    if (tile == 0 && tid == 0) ws[PROJ_WS_DIRTY] = fallback ? 1 : 0;
+    if (tile == 0 && tid == 0) {
+        ws[PROJ_WS_DIRTY] = fallback ? (int)(unsigned)(plane_floats & 0xffffffffll) : 0;
+        ws[PROJ_WS_DIRTY + 1] = fallback ? (int)(plane_floats >> 32) : 0;
+    }
     int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
     const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5], e6 = entry[6];
     const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
@@ -865,7 +876,7 @@ __device__ __forceinline__ int mask_next(const unsigned long long* m, int j) {
 __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
     int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
-    const bool fallback = ws[PROJ_WS_DIRTY] != 0;
+    const bool fallback = proj_dirty_floats(ws) != 0;
     // one workgroup per tile; K1 has left a word per tile: 0 = no holes (most tiles: the workgroup leaves at once),
     // 1 = holes, 3 = holes and negative counts (non-zero, yet holes: the counts are read then)
     const int tile = blockIdx.x;
@@ -1082,10 +1093,16 @@ struct ProjBuffers { int* words; int* bits; float* planes; };
 static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
     // the header, the tile records and the scratch planes carry state between calls and start at zero;
     // the list and the bitmaps are rewritten by every call
-    p->words = static_cast<int*>(ws_get(st, WS_PROJ_WORDS, z.words * sizeof(int), true, nullptr));
+    bool fresh_words = false, fresh_planes = false;
+    size_t plane_bytes = 0;
+    p->words = static_cast<int*>(ws_get(st, WS_PROJ_WORDS, z.words * sizeof(int), true, &fresh_words));
     p->bits = static_cast<int*>(ws_get(st, WS_PROJ_BITS, z.bit_words * sizeof(int), false, nullptr));
-    p->planes = static_cast<float*>(ws_get(st, WS_PROJ_PLANES, z.plane_floats * sizeof(float), true, nullptr));
-    return p->words && p->bits && p->planes;
+    p->planes = static_cast<float*>(ws_get(st, WS_PROJ_PLANES, z.plane_floats * sizeof(float), true, &fresh_planes, &plane_bytes));
+    if (!(p->words && p->bits && p->planes)) return false;
+    // the header that says how much of the planes is dirty lives in `words`: a new (zeroed) header beside planes that
+    // were kept would forget it
+    if (fresh_words && !fresh_planes && hipMemsetAsync(p->planes, 0, plane_bytes, st) != hipSuccess) return false;
+    return true;
 }
 
 // every in-plane element offset of a [*, *, h, w] tensor with row stride sh fits 31 bits
@@ -1125,10 +1142,10 @@ static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, fl
                         sc.b % 4 == 0 && sc.h % 4 == 0) ? 1 : 0;
     if (vec_in)
         hipLaunchKernelGGL((proj_pull<DEPTH, false, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
-                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes);
+                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     else
         hipLaunchKernelGGL((proj_pull<DEPTH, UP, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
-                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes);
+                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
     hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_FIN_THREADS), 0, st, count, out, g,

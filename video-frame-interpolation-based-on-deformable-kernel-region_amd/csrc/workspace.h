@@ -27,6 +27,7 @@ enum WsSlot {
 // Returns a device buffer of at least `bytes` bytes for (current device, stream, slot), or nullptr.
 // *fresh is set when the buffer was (re)allocated by this call; with zero_on_alloc the new buffer has
 // been zero-filled by a hipMemsetAsync on `stream` before it is returned.
-void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, bool* fresh);
+// *capacity, when asked for, is the size of the returned buffer (at least `bytes`).
+void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, bool* fresh, size_t* capacity = nullptr);
 
 }  // namespace vfi

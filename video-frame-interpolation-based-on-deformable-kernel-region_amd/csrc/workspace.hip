@@ -17,8 +17,9 @@ static std::mutex g_mutex;
 static std::deque<WsEntry> g_entries;             // deque: entries stay put when another stream adds one
 static std::vector<std::pair<int, void*>> g_retired;   // (device, pointer) outgrown but possibly still replayed
 
-void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, bool* fresh) {
+void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, bool* fresh, size_t* capacity) {
     if (fresh) *fresh = false;
+    if (capacity) *capacity = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -29,7 +30,10 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
         g_entries.push_back(WsEntry{dev, stream, {}, {}});
         e = &g_entries.back();
     }
-    if (e->bytes[slot] >= bytes && e->ptr[slot]) return e->ptr[slot];
+    if (e->bytes[slot] >= bytes && e->ptr[slot]) {
+        if (capacity) *capacity = e->bytes[slot];
+        return e->ptr[slot];
+    }
     // grow generously (x1.25) so that a sequence of slightly larger frames does not retire a buffer each time
     size_t want = bytes + bytes / 4;
     want = (want + 255) & ~(size_t)255;
@@ -43,6 +47,7 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
     e->ptr[slot] = p;
     e->bytes[slot] = want;
     if (fresh) *fresh = true;
+    if (capacity) *capacity = want;
     return p;
 }
 
