@@ -2,7 +2,8 @@
 """Soak of the other hot-path entry points against the CPU oracle on random shapes (larger and more varied than the
 hypothesis-drawn unit tests): correlation fp32 and half (every k = 1 kernel: flat, tiled, 16-byte rows), PWC-Net's warp
 alone and feeding the correlation in one launch, the x4-upsample fused into the projection, MinDepthFlowProjection,
-Interpolation, the FilterInterpolation backward (per-pixel gradients bit-exact, image gradient within GRAD_TOL).
+Interpolation, and the backward passes of FilterInterpolation, the projections, the correlation and Interpolation
+(per-pixel gradients bit-exact, scattered image gradients within GRAD_TOL).
     python tests/soak_ops.py [cases] [seed]        (not collected by pytest; the oracle is the checker)
 """
 import os
@@ -87,6 +88,30 @@ for it in range(cases):
         r1, r2, r3 = oracle.filterinterp_ori_bwd(f1, flo, filt, gout, fmad=1)
         check("FilterInterpolation backward", np.array_equal(cpu(gi2), r2) and np.array_equal(cpu(gi3), r3)
               and np.abs(cpu(gi1) - r1).max() <= 2e-6 * max(1.0, np.abs(r1).max()), info)
+    # ---- backward passes: projection (bit-exact), correlation (bit-exact), Interpolation (image gradient within GRAD_TOL)
+    dep = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+    po, pc = oracle.depthflowproj_fwd(flo, dep, 0)
+    cnt = np.where(pc > 0, pc, 1).astype(f32)
+    g2o = rng.standard_normal((B, 2, H, W)).astype(f32)
+    gf = torch.zeros((B, 2, H, W), device=dev)
+    assert cabi.flowprojection_backward(gfl, gpu(cnt), gpu(g2o), gf) == 0
+    check("FlowProjection backward", np.array_equal(cpu(gf), oracle.flowproj_bwd(flo, cnt, g2o)), info)
+    gf.zero_()
+    gd = torch.zeros((B, 1, H, W), device=dev)
+    assert cabi.depthflowprojection_backward(gfl, gpu(dep), gpu(cnt), gpu(po), gpu(g2o), gf, gd) == 0
+    rf, rd = oracle.depthflowproj_bwd(flo, dep, cnt, po, g2o)
+    check("DepthFlowProjection backward", np.array_equal(cpu(gf), rf) and np.array_equal(cpu(gd), rd), info)
+    if C <= 19 and H * W <= 10000:
+        gco = rng.standard_normal((B, 81, H, W)).astype(f32)
+        c1, c2 = cabi.correlation_backward(g1, g2, gpu(gco), 4, 1, 4, 1, 1)
+        r1, r2 = oracle.correlation_bwd(f1, f2, gco, 4, 1, 4, 1, 1)
+        check("correlation backward", np.array_equal(cpu(c1), r1) and np.array_equal(cpu(c2), r2), info)
+    if C <= 8:
+        gio = rng.standard_normal((B, C, H, W)).astype(f32)
+        gi, gfl2 = torch.zeros((B, C, H, W), device=dev), torch.zeros((B, 2, H, W), device=dev)
+        assert cabi.interpolation_backward(g1, gfl, gpu(gio), gi, gfl2) == 0
+        ri, rfl = oracle.interp_bwd(f1, flo, gio, fmad=1)
+        check("Interpolation backward", np.array_equal(cpu(gfl2), rfl) and np.abs(cpu(gi) - ri).max() <= 2e-6 * max(1.0, np.abs(ri).max()), info)
     if it % 20 == 19:
         print("%d cases, %d mismatches" % (it + 1, bad), flush=True)
 print("done: %d cases, %d mismatches" % (cases, bad))
