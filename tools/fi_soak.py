@@ -64,7 +64,7 @@ for it in range(cases):
     # other filter sizes (staged fs = 2, 5, 6 against the direct kernel) and the three deformable variants (staged against
     # the general kernel), on a dense copy, every few cases
     if it % 3 == 0 and H * W <= 120000:
-        imgd = img.contiguous()
+        imgd = torch.empty(B, C, H, W, device=dev).copy_(img)
         for fs in (2, 5, 6):
             fl = torch.rand(B, fs * fs, H, W, generator=gen).to(dev)
             a, b_ = torch.full_like(imgd, float("nan")), torch.empty_like(imgd)
@@ -78,6 +78,26 @@ for it in range(cases):
             assert cabi.filterinterp_forward_defor(variant, imgd, flow, i3, i4, a) == 0
             assert cabi.filterinterp_forward_defor(variant, imgd, flow, i3, i4, b_, general=True) == 0
             ok = ok and same(a, b_)
+    # fp16 storage: the staged kernel against the direct one (folded weights: within the fp16 tolerance of the tests), and the
+    # fused blend (second launch's epilogue) against two launches and torch's three elementwise ops, bit for bit
+    if it % 2 == 0:
+        imgd = torch.empty(B, C, H, W, device=dev).copy_(img)      # (dense: `contiguous()` keeps a B = 1 slice's batch stride)
+        i16 = imgd.half()
+        a16, b16 = torch.zeros_like(i16), torch.zeros_like(i16)
+        assert cabi.filterinterp_forward_ori_f16(i16, flow, filt, a16) == 0
+        assert cabi.filterinterp_forward_ori_f16(i16, flow, filt, b16, direct=True) == 0
+        ok = ok and bool(((a16.float() - b16.float()).abs() <= 2e-3 * b16.float().abs().clamp(min=1.0)).all())
+        if C <= 4:
+            img2 = torch.randn(B, C, H, W, generator=gen).to(dev)
+            flow2 = (flow * -0.7).contiguous()
+            filt2 = torch.rand(B, 16, H, W, generator=gen).to(dev)
+            o0, o2, bl = (torch.full_like(imgd, float("nan")) for _ in range(3))
+            rc = cabi.filterinterp_blend_forward(imgd, img2, flow, flow2, filt, filt2, bl, o0, o2, 0.75, 0.25)
+            assert rc == 0, "blend rc %r: B=%d C=%d H=%d W=%d %s" % (rc, B, C, H, W, kind)
+            r0, r2 = torch.empty_like(imgd), torch.empty_like(imgd)
+            assert cabi.filterinterp_forward_ori(imgd, flow, filt, r0, direct=True) == 0
+            assert cabi.filterinterp_forward_ori(img2, flow2, filt2, r2, direct=True) == 0
+            ok = ok and same(o0, r0) and same(o2, r2) and same(bl, r0 * 0.75 + r2 * 0.25)
     if not ok:
         bad += 1
         print("MISMATCH case %d: B=%d C=%d H=%d W=%d %s" % (it, B, C, H, W, kind), flush=True)

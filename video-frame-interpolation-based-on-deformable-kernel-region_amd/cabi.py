@@ -518,7 +518,8 @@ def depthflowprojection_forward_up4(flow_q, input2, count, output, mul0, mul1, f
 
 
 def _same_strides(a, b):
-    return a.shape == b.shape and a.stride() == b.stride()
+    """same layout: the stride of a dimension of size 1 is never used (torch leaves it arbitrary, e.g. after slicing)"""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n != 1)
 
 
 def filterinterp_blend_forward(ref0, ref2, flow0, flow2, filt0, filt2, blend, out0, out2, w0, w2):
