@@ -112,6 +112,42 @@ for it in range(cases):
         assert cabi.interpolation_backward(g1, gfl, gpu(gio), gi, gfl2) == 0
         ri, rfl = oracle.interp_bwd(f1, flo, gio, fmad=1)
         check("Interpolation backward", np.array_equal(cpu(gfl2), rfl) and np.abs(cpu(gi) - ri).max() <= 2e-6 * max(1.0, np.abs(ri).max()), info)
+    # ---- SeparableConv / SeparableConvFlow forward + backward (filter sizes 1 .. 13), deformable backward
+    fs = int(rng.choice([1, 2, 5, 9, 13]))
+    if C == 3 and H >= fs and W >= fs and H * W <= 20000:        # (three channels: separableconv_cuda.cc refuses anything else)
+        oh, ow = H - fs + 1, W - fs + 1
+        v = rng.random((B, fs, oh, ow), dtype=f32)
+        hh = rng.random((B, fs, oh, ow), dtype=f32)
+        gv, gh = gpu(v), gpu(hh)
+        so = torch.full((B, C, oh, ow), float("nan"), device=dev)
+        assert cabi.separableconv_forward(g1, gv, gh, so) == 0
+        check("SeparableConv", np.array_equal(cpu(so), oracle.sepconv_fwd(f1, v, hh, fmad=1)), info + " fs=%d" % fs)
+        fo = torch.full((B, 2, oh, ow), float("nan"), device=dev)
+        assert cabi.separableconvflow_forward(g1, gv, gh, fo) == 0
+        check("SeparableConvFlow", np.array_equal(cpu(fo), oracle.sepconvflow_fwd(v, hh, H, W, fmad=1)), info + " fs=%d" % fs)
+        sgo = rng.standard_normal((B, C, oh, ow)).astype(f32)
+        s1_, s2_, s3_ = torch.zeros_like(g1), torch.zeros_like(gv), torch.zeros_like(gh)
+        assert cabi.separableconv_backward(g1, gv, gh, gpu(sgo), s1_, s2_, s3_) == 0
+        q1, q2, q3 = oracle.sepconv_bwd(f1, v, hh, sgo)
+        check("SeparableConv backward", np.array_equal(cpu(s1_), q1) and np.array_equal(cpu(s2_), q2) and np.array_equal(cpu(s3_), q3), info + " fs=%d" % fs)
+    if C <= 3 and H * W <= 6000:
+        filt = rng.random((B, 16, H, W), dtype=f32)
+        off = (rng.standard_normal((B, 32, H, W)) * 0.7).astype(f32)
+        dgo = rng.standard_normal((B, C, H, W)).astype(f32)
+        for variant in (0, 1, 2):
+            d1, d2 = torch.zeros((B, C, H, W), device=dev), torch.zeros((B, 2, H, W), device=dev)
+            do = torch.zeros((B, 32, H, W), device=dev)
+            if variant == 2:
+                err = cabi.filterinterp_backward_defor(variant, g1, gfl, gpu(off), None, gpu(dgo), d1, d2, do, None)
+                dfl = None
+            else:
+                dfl = torch.zeros((B, 16, H, W), device=dev)
+                err = cabi.filterinterp_backward_defor(variant, g1, gfl, gpu(filt), gpu(off), gpu(dgo), d1, d2, dfl, do)
+            assert err == 0
+            e1, e2, e3, e4 = oracle.filterinterp_defor_bwd(variant, f1, flo, filt, off, dgo, fmad=1)
+            okb = (np.abs(cpu(d1) - e1).max() <= 2e-6 * max(1.0, np.abs(e1).max()) and np.array_equal(cpu(d2), e2) and np.array_equal(cpu(do), e4)
+                   and (variant == 2 or np.array_equal(cpu(dfl), e3)))
+            check("deformable backward %d" % variant, okb, info)
     if it % 20 == 19:
         print("%d cases, %d mismatches" % (it + 1, bad), flush=True)
 print("done: %d cases, %d mismatches" % (cases, bad))
