@@ -202,6 +202,20 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res["t"] >= 3 * 0.02 * 0.9            # rank 1 sleeps 0.02 s per step: MAX, not rank 0's 0.03 s
 
 
+def test_same_strides_ignores_size_one_dimensions():
+    """torch leaves the stride of a size-1 dimension arbitrary (a B = 1 channel slice keeps the wide tensor's batch stride
+    and still counts as contiguous): the glue entry points compare layouts without it."""
+    import torch
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import cabi
+    wide = torch.zeros(1, 7, 4, 6)
+    sl, dense = wide[:, 2:5], torch.zeros(1, 3, 4, 6)
+    assert sl.is_contiguous() and sl.stride(0) != dense.stride(0)
+    assert cabi._same_strides(sl, dense)
+    assert not cabi._same_strides(torch.zeros(2, 7, 4, 6)[:, 2:5], torch.zeros(2, 3, 4, 6))
+    assert not cabi._same_strides(dense, torch.zeros(1, 3, 4, 5))
+
+
 def test_bench_launcher_starts_its_own_ranks():
     """`bench.py --gpus 2` with no RANK in the environment starts two ranks itself (gloo timing join) and prints ONE
     JSON line whose n_gpus is the number of ranks that ran; --stub-step replaces the GPU step by a sleep."""
