@@ -3,6 +3,7 @@
 frames.  Dyadic inputs (multiples of 1/8, weights multiples of 1/16): every sum is exact in any order, so count and flow
 must equal the oracle's bit for bit; non-dyadic inputs: within 1e-4 and identical from run to run.
     python tests/soak_projection.py [cases] [seed]        (not collected by pytest; the oracle is the checker, so it lives under tests/)
+    --lib <path> picks a development build of the library
 """
 import os
 import sys
@@ -12,6 +13,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import vfidkr_amd  # noqa: E402,F401
+if "--lib" in sys.argv:         # a development build of the library (tools/mkvariant.sh)
+    _i = sys.argv.index("--lib")
+    vfidkr_amd.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from vfidkr_amd import cabi  # noqa: E402
 from oracle import cpu_oracle as oracle  # noqa: E402  (test infrastructure: the checker)
 oracle.build()

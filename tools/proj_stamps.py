@@ -42,7 +42,7 @@ print("end    min %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (end.min(), np.median
 life = end - start
 print("life   min %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (life.min(), np.median(life), np.percentile(life, 90), life.max()))
 cyc = t3 - t0
-for name, a, b in (("prologue+loop", t0, t1), ("barrier+sums", t1, t2), ("epilogue", t2, t3)):
+for name, a, b in (("start..accumulated", t0, t1), ("..tile stored", t1, t2), ("..end", t2, t3)):
     d = b - a
     print("%-14s median %8.0f cycles (%.0f %% of life)" % (name, np.median(d), 100.0 * np.median(d) / np.median(cyc)))
 hw = buf[:, 6].astype(np.int64)
@@ -59,7 +59,7 @@ late = start > np.percentile(start, 50)
 print("workgroups starting after the median start: %d, their mean start %.2f us" % (late.sum(), start[late].mean()))
 order = np.argsort(start)
 print("start time of workgroup #: " + "  ".join("%d: %.2f" % (i, start[order[i]]) for i in (0, 500, 1000, 1500, 2000, 2100, 2200, nt - 1)))
-for name, a, b in (("prologue+loop", t0, t1), ("barrier+sums", t1, t2), ("epilogue", t2, t3)):
+for name, a, b in (("start..accumulated", t0, t1), ("..tile stored", t1, t2), ("..end", t2, t3)):
     d = (b - a)
     print("%-14s cycles: p10 %7.0f p50 %7.0f p90 %7.0f max %7.0f" % (name, np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max()))
 tx_n = (w + 63) // 64

@@ -202,6 +202,24 @@ __device__ __forceinline__ bool pix_target(float fx, float fy, int x, int y, uns
     return (unsigned)__float_as_int(x2) <= wbits && (unsigned)__float_as_int(y2) <= hbits;
 }
 
+// Workgroup -> work item.  Workgroups are dealt round-robin over the 8 XCDs (observed on gfx950: block b runs on XCD
+// b % 8 in every launch; speed only -- any dealing gives the same results), each XCD with an L2 of its own.  Item =
+// the b/8-th of XCD b%8's contiguous eighth of the raster order: an XCD owns one horizontal band of the frame in
+// K0, K1 and K2 alike, so the flow K0 has just read is in the L2 that K1's workgroups read their source
+// rectangles through, and the counts, flows and bitmaps K1 writes are in the L2 K2 searches them through.  A
+// bijection of [0, n) for every n.
+#ifndef PROJ_BANDS
+#define PROJ_BANDS 1
+#endif
+__device__ __forceinline__ int band_item(int bid, int n) {
+#if PROJ_BANDS
+    const int x = bid & 7, k = bid >> 3, base = n >> 3, rem = n & 7;
+    return x * base + min(x, rem) + k;
+#else
+    return bid;
+#endif
+}
+
 // min / max over each row of 16 lanes (four DPP row_shr steps); the result is in lane 15 of the row
 #define PROJ_ROW_STEP(OP, CTRL) v = OP(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false))
 __device__ __forceinline__ int row16_min(int v) {
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
         const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(dirty, lo + chunk);
         for (int64_t i = lo + threadIdx.x; i < hi; i += 64) planes[i] = 0.0f;
     }
-    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tile = band_item(blockIdx.x, gridDim.x), lane = threadIdx.x;
     const int per_img = g.tiles_x * g.tiles_y;
     const int b = tile / per_img;
     const int trem = tile - b * per_img;
@@ -338,18 +356,13 @@ __device__ __forceinline__ int quad_max(int v) { PROJ_QUAD_STEP(max, 0xb1); PROJ
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int groups_x, int* __restrict__ ws,
                                                   float* __restrict__ planes, int64_t plane_floats) {
-    const int64_t dirty = proj_dirty_floats(ws);
-    if (dirty != 0) {                                       // (see proj_scan)
-        const int64_t chunk = (dirty + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(dirty, lo + chunk);
-        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
-    }
     __shared__ int sblk[16][7];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 112) sblk[tid / 7][tid % 7] = (tid % 7 == 0 || tid % 7 == 2) ? INT_MAX : (tid % 7 == 1 || tid % 7 == 3) ? INT_MIN : 0;
     const int per_img = groups_x * g.tiles_y;
-    const int b = blockIdx.x / per_img;
-    const int rem = blockIdx.x - b * per_img;
+    const int item = band_item(blockIdx.x, gridDim.x);
+    const int b = item / per_img;
+    const int rem = item - b * per_img;
     const int tyi = rem / groups_x, gxi = rem - tyi * groups_x;
     const int x0 = gxi * 4 * PROJ_TW + 4 * lane, y0 = tyi * PROJ_TH, yw = y0 + 4 * wave;
     const ProjPlanes pl = proj_planes<DEPTH, false>(src, b, g.h, g.w);
@@ -361,6 +374,13 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         qx[r] = buf_f32x4(pl.f0, x0 * 4, so);
         qy[r] = buf_f32x4(pl.f1, x0 * 4, so);
         if constexpr (DEPTH) qd[r] = buf_f32x4(pl.d, x0 * 4, min(yw + r, g.h - 1) * src.dh * 4);
+    }
+    // (behind the flow loads, so that they are in flight while the header word arrives)
+    const int64_t dirty = proj_dirty_floats(ws);
+    if (dirty != 0) {                                       // (see proj_scan)
+        const int64_t chunk = (dirty + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(dirty, lo + chunk);
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
     }
     __syncthreads();
     int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
@@ -439,6 +459,9 @@ template <> struct ProjCountCell<true> { typedef unsigned long long type; };    
 #define PROJ_VS 66                                  // grid row pitch of the 8-byte planes: rows start 16-byte aligned
 #define PROJ_CS4 68                                 // ... of the 4-byte count plane
 #define PROJ_NW (PROJ_PULL_THREADS / 64)            // waves per workgroup
+#ifndef PROJ_ST_AUX
+#define PROJ_ST_AUX 2                               // cache policy of K1's result stores: nt (0 = default, 16 = sc1: K1 1.4 us slower at 1080p)
+#endif
 #define PROJ_EPI_ITERS (PROJ_TH / (4 * PROJ_NW))    // a wave writes four rows per instruction (16 lanes x 16 bytes each)
 template <bool DEPTH> struct ProjLds {
     static constexpr int cs = DEPTH ? PROJ_VS : PROJ_CS4;                      // count plane pitch
@@ -446,6 +469,63 @@ template <bool DEPTH> struct ProjLds {
     static constexpr int acc_bytes = accc_off + PROJ_AH * cs * (DEPTH ? 8 : 4);
     static constexpr int total = acc_bytes + PROJ_TH * 8 + 16;                 // + row bitmaps + three counters
 };
+
+// The fallback of K1 (a block of K0 reached too many tiles): the reference's own scheme -- this tile as SOURCE tile,
+// global atomics into the dense scratch planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
+template <bool DEPTH, bool UP, int NW>
+__device__ __forceinline__ void pull_fallback(const ProjSrc& src, const ProjPlanes& pl, const ProjGeom& g, float* __restrict__ planes,
+                                              int b, int ox0, int oy0, int lane, int wave) {
+    const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
+    float* o0 = planes + (int64_t)b * g.h * g.w;
+    float* o1 = o0 + npx;
+    float* cn = o1 + npx;
+    const int x = ox0 + lane;
+    for (int r = 0; r < PROJ_TH / NW; ++r) {
+        const int y = oy0 + wave * (PROJ_TH / NW) + r;
+        if (x >= g.w || y >= g.h) continue;
+        float fx, fy;
+        const ProjPix<UP> p = pix_load<DEPTH, UP>(src, pl, x, 0, y);
+        pix_flow<UP>(src, p, x, y, fx, fy);
+        int L, T;
+        if (!pix_target(fx, fy, x, y, wbits, hbits, L, T)) continue;
+        const int R = min(L + 1, g.w - 1), Bm = min(T + 1, g.h - 1);
+        const float ax = DEPTH ? -p.d * fx : -fx, ay = DEPTH ? -p.d * fy : -fy, ac = p.d;   // (:75-88; depth :74-91)
+        const int64_t oT = (int64_t)T * g.w, oB = (int64_t)Bm * g.w;
+        atomicAdd(&o0[oT + L], ax); atomicAdd(&o0[oT + R], ax); atomicAdd(&o0[oB + L], ax); atomicAdd(&o0[oB + R], ax);
+        atomicAdd(&o1[oT + L], ay); atomicAdd(&o1[oT + R], ay); atomicAdd(&o1[oB + L], ay); atomicAdd(&o1[oB + R], ay);
+        atomicAdd(&cn[oT + L], ac); atomicAdd(&cn[oT + R], ac); atomicAdd(&cn[oB + L], ac); atomicAdd(&cn[oB + R], ac);
+    }
+}
+
+// The tail of K1, after the barrier behind the tile's stores: the tile's rows of the two "count != 0" bitmaps (from the
+// row words collected in LDS) and its word for K2.
+template <int THREADS>
+__device__ __forceinline__ void pull_bitmaps(const ProjGeom& g, int* __restrict__ ws, int* __restrict__ bits, const unsigned* s_rowbits,
+                                             const int* s_misc, int b, int txi, int tyi, int ox0, int oy0, int tile, int tid) {
+    // the row-packed bitmap: two words per tile row
+    if (tid < 2 * PROJ_TH) {
+        const int yl = tid >> 1, wi = txi * 2 + (tid & 1);
+        if (oy0 + yl < g.h && wi < g.rmw) bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + wi] = (int)s_rowbits[tid];
+    }
+    // the column-packed one: a column word holds two tiles' rows, each tile stores its own 16-bit half (and the
+    // unused halves that pad a column line to whole 16-byte groups, if it is the last tile of the column)
+    for (int t = tid; t < PROJ_TW; t += THREADS)
+        if (ox0 + t < g.w) {
+            unsigned colbits = 0u;
+#pragma unroll
+            for (int r = 0; r < PROJ_TH; ++r) colbits |= ((s_rowbits[r * 2 + (t >> 5)] >> (t & 31)) & 1u) << r;
+            unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + t) * g.cmw) * 2;
+            half[tyi] = (unsigned short)colbits;
+            if (tyi == g.tiles_y - 1)
+                for (int k = tyi + 1; k < 2 * g.cmw; ++k) half[k] = 0;
+        }
+    // the tile's word for K2: 0 = no holes, 1 = holes, 3 = holes and negative counts (non-zero, yet holes: K2 then
+    // reads the counts).  (A list of the tiles with holes, appended with one atomic per tile, costs ~12 ns per tile
+    // on its counter -- measured: 24 us more on a rough field where most tiles have holes.)
+    if (tid == 0) ws[g.off_list + tile] = s_misc[1] ? (s_misc[2] ? 3 : 1) : 0;
+}
 
 // one source pixel into the grid
 // cls / ncls / emax: with depth, only the sources of weight class cls are taken (see proj_pull)
@@ -485,7 +565,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     ccell* accc = reinterpret_cast<ccell*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::accc_off);
     unsigned* s_rowbits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + ProjLds<DEPTH>::acc_bytes);   // [16][2]
     int* s_misc = reinterpret_cast<int*>(s_rowbits + 2 * PROJ_TH);     // [0] most addends in a cell, [1] holes, [2] negative counts
-    const int tile = blockIdx.x;
+    const int tile = band_item(blockIdx.x, gridDim.x);
     const int per_img = g.tiles_x * g.tiles_y;
     const int b = tile / per_img;
     const int trem = tile - b * per_img;
@@ -510,28 +590,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     if (fallback) {
         __syncthreads();
         if (tid < 7) entry[tid] = 0;
-        // the reference's own scheme: this tile as SOURCE tile, global atomics into the dense scratch
-        // planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
-        const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
-        float* o0 = planes + (int64_t)b * g.h * g.w;
-        float* o1 = o0 + npx;
-        float* cn = o1 + npx;
-        const int x = ox0 + lane;
-        for (int r = 0; r < PROJ_TH / PROJ_NW; ++r) {
-            const int y = oy0 + wave * (PROJ_TH / PROJ_NW) + r;
-            if (x >= g.w || y >= g.h) continue;
-            float fx, fy;
-            const ProjPix<UP> p = pix_load<DEPTH, UP>(src, pl, x, 0, y);
-            pix_flow<UP>(src, p, x, y, fx, fy);
-            int L, T;
-            if (!pix_target(fx, fy, x, y, wbits, hbits, L, T)) continue;
-            const int R = min(L + 1, g.w - 1), Bm = min(T + 1, g.h - 1);
-            const float ax = DEPTH ? -p.d * fx : -fx, ay = DEPTH ? -p.d * fy : -fy, ac = p.d;   // (:75-88; depth :74-91)
-            const int64_t oT = (int64_t)T * g.w, oB = (int64_t)Bm * g.w;
-            atomicAdd(&o0[oT + L], ax); atomicAdd(&o0[oT + R], ax); atomicAdd(&o0[oB + L], ax); atomicAdd(&o0[oB + R], ax);
-            atomicAdd(&o1[oT + L], ay); atomicAdd(&o1[oT + R], ay); atomicAdd(&o1[oB + L], ay); atomicAdd(&o1[oB + R], ay);
-            atomicAdd(&cn[oT + L], ac); atomicAdd(&cn[oT + R], ac); atomicAdd(&cn[oB + L], ac); atomicAdd(&cn[oB + R], ac);
-        }
+        pull_fallback<DEPTH, UP, PROJ_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
         return;
     }
 
@@ -775,9 +834,9 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
                 const proj_v4i vx4 = {__float_as_int(vxa[0]), __float_as_int(vxa[1]), __float_as_int(vxa[2]), __float_as_int(vxa[3])};
                 const proj_v4i vy4 = {__float_as_int(vya[0]), __float_as_int(vya[1]), __float_as_int(vya[2]), __float_as_int(vya[3])};
                 const proj_v4i c4 = {__float_as_int(ca[0]), __float_as_int(ca[1]), __float_as_int(ca[2]), __float_as_int(ca[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(vx4, ro0, vo, so0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(vy4, ro1, vo, so0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(c4, rcn, voc, soc, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(vx4, ro0, vo, so0, PROJ_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(vy4, ro1, vo, so0, PROJ_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(c4, rcn, voc, soc, PROJ_ST_AUX);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -792,26 +851,402 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     if (holes) atomicAdd(&s_misc[1], holes);
     if (negs) atomicAdd(&s_misc[2], negs);
     __syncthreads();
-    // the row-packed bitmap: two words per tile row
-    if (tid < 2 * PROJ_TH) {
-        const int yl = tid >> 1, wi = txi * 2 + (tid & 1);
-        if (oy0 + yl < g.h && wi < g.rmw) bits[g.rowmap + (b * g.h + oy0 + yl) * g.rmw + wi] = (int)s_rowbits[tid];
+    pull_bitmaps<PROJ_PULL_THREADS>(g, ws, bits, s_rowbits, s_misc, b, txi, tyi, ox0, oy0, tile, tid);
+#ifdef PROJ_STAMPS
+    if (tid == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + g.off_list + g.ntiles + (g.ntiles & 1)) + (int64_t)tile * 8;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st[0] = st_t0; st[1] = st_t1; st[2] = st_t2; st[3] = __builtin_amdgcn_s_memtime();
+        st[4] = st_r0; st[5] = __builtin_amdgcn_s_memrealtime(); st[6] = hwid; st[7] = (unsigned long long)xcc | ((st_ta - st_t0) << 8);
     }
-    // the column-packed one: a column word holds two tiles' rows, each tile stores its own 16-bit half (and the
-    // unused halves that pad a column line to whole 16-byte groups, if it is the last tile of the column)
-    if (tid < PROJ_TW && ox0 + tid < g.w) {
-        unsigned colbits = 0u;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K1, lean (round 3): full-resolution flow with 16-byte aligned rows -- what FlowProjection / DepthFlowProjection are
+// called with.  Same tile and same grid of exact integer sums as proj_pull, written for the fewest instructions per
+// pixel, because that is what bounds the kernel: all 2232 tiles of a 1080p frame are resident at once, 4.5 waves per
+// SIMD, and a wave of proj_pull executes ~2000 vector instructions for its ~11 source and 8 output pixels per lane
+// (SQ_INSTS_VALU; the workgroups dispatched first finish first -- age-ordered issue -- which is what the in-kernel
+// stamps show: tools/proj_stamps.py).  Here:
+//  * a source pixel is tested ONCE: "valid target" (0 <= x2 <= w - 1) and "target inside this tile's grid" are one
+//    interval per axis, tested on the float's bits (non-negative floats order like their bit patterns: one subtract, one
+//    unsigned compare).  No lane predicates beside it: lanes past the frame or past the strip carry NaN coordinates,
+//    and an in-frame pixel outside the rectangle cannot reach the tile (K0's rectangle holds every pixel that can);
+//  * grid cell address = (T * pitch + L) * 8 + one uniform constant; the count plane has the value plane's 8-byte
+//    pitch, so its address is the same register + an immediate;
+//  * the y half of a value addend is biased by 2^25 (non-negative: the 64-bit add never borrows from the x half; the
+//    epilogue subtracts count * 2^25), which saves the sign fix-up per pixel and the packed-half recovery per cell;
+//  * the 2x2 sums of a lane's four cells share their five column sums; the frame's last row / column (R == L, B == T:
+//    the reference adds twice) is fixed up in the tiles that touch them only;
+//  * FlowProjection divides by an integer count <= 32 times a power of two: the reciprocal is rcp + one Newton step
+//    (= the correctly rounded 1 / n for every n <= 32: tests), the quotient one multiply and one correction per
+//    component (Markstein: correctly rounded, the same bits as an IEEE division);
+//  * the record comes through the scalar cache (one s_load_dwordx8), tile coordinates from a 3-D grid (no divisions);
+//  * the busiest-cell check (more than 32 addends in a cell: accumulate again with a coarser scale) rides on the
+//    epilogue's own count sums and on the barrier before the bitmaps instead of a pass and a barrier of its own: the
+//    tile is written as if every cell were fine, and written again in the rare case one was not.
+// LDS layout.  gfx950 allots LDS in granules of 1280 bytes and nine workgroups per CU (all 2232 tiles of a 1080p frame resident
+// at once, no second round) may use 14 granules each = 17,920 bytes.  FlowProjection: 8-byte value cells at a pitch of 66 (rows
+// 16-byte aligned: ds_read_b128) + 4-byte count cells at a pitch of 68 = 13,744 bytes.  DepthFlowProjection needs 8-byte count
+// cells ({weight sum, addends}): with both planes at a pitch of 65 (rows 8-byte aligned: ds_read2_b64) it would fit in 17,824 bytes,
+// but its 127 registers allow eight workgroups per CU anyway (at 96, nine per CU, it spills and takes 30.8 instead of 25 us
+// at 1080p): pitch 66, 18,096 bytes, a short second round of 184 tiles.
+template <bool DEPTH> struct PlLds {
+    static constexpr int P = 66;                                               // value plane pitch, cells
+    static constexpr int PC = DEPTH ? 66 : 68;                                 // count plane pitch, cells
+    static constexpr int CB = DEPTH ? 8 : 4;                                   // bytes per count cell
+    static constexpr int vplane = (PROJ_AH * P * 8 + 15) & ~15;
+    static constexpr int cplane = (PROJ_AH * PC * CB + 15) & ~15;
+    static constexpr int planes = vplane + cplane;
+    static constexpr int total = planes + PROJ_TH * 8 + 16;                    // + row bitmaps + four counters
+};
+static_assert(PlLds<false>::total <= 17920, "nine workgroups per CU");
+#define PL_BIAS (1 << PROJ_ADD_BITS)
+#ifndef PL_THREADS
+#define PL_THREADS 128
+#endif
+#ifndef PL_CH
+#define PL_CH 4                                     // row steps whose loads are in flight together (depth: half, for the registers)
+#endif
+#define PL_NW (PL_THREADS / 64)
+#define PL_EPI (PROJ_TH / (4 * PL_NW))              // a wave writes four rows per pass
+
+typedef int pl_v8i __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned long long* pl_lds64_t;
+typedef __attribute__((address_space(3))) unsigned* pl_lds32_t;
+
+// a / d for an integer |a| < 2^31 (converted exactly, or rounded once) and d = n * 2^k, n a positive integer: with r the
+// correctly rounded 1 / d, q0 = a * r is within an ulp of a / d, the remainder is exact and the corrected quotient is
+// RN(a / d) (Markstein's theorem) -- the bits of an IEEE division.  (k keeps everything in the normal range: the host
+// path clamps it.)
+__device__ __forceinline__ float pl_div(float a, float d, float r) {
+    const float q0 = a * r;
+    const float rem = fmaf(-d, q0, a);
+    return fmaf(rem, r, q0);
+}
+__device__ __forceinline__ float pl_rcp(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
+    ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
+    int64_t cb, int ch, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats) {
+    typedef PlLds<DEPTH> LY;
+    constexpr int P = LY::P, PC = LY::PC;
+    __shared__ uint4 lds[LY::total / 16];
+    char* const lbase = reinterpret_cast<char*>(lds);
+    unsigned* s_rowbits = reinterpret_cast<unsigned*>(lbase + LY::planes);            // [16][2]
+    int* s_misc = reinterpret_cast<int*>(s_rowbits + 2 * PROJ_TH);                    // [0] most addends in a cell, [1] holes, [2] negative counts
+#if PROJ_BANDS
+    const int tile = band_item(blockIdx.x, gridDim.x);
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+#else
+    const int txi = blockIdx.x, tyi = blockIdx.y, b = blockIdx.z;
+    const int tile = (b * g.tiles_y + tyi) * g.tiles_x + txi;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ox0 = txi * PROJ_TW, oy0 = tyi * PROJ_TH;
+    int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
+    // the record and the fallback word through the scalar cache (invalidated at kernel start; K0 wrote them by atomics)
+#ifdef PROJ_STAMPS          // development build only: when and where each workgroup ran (tools/proj_stamps.py)
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_t1 = 0, st_t2 = 0;
+#endif
+    pl_v8i rec;
+    int fb_word;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0" : "=&s"(rec), "=&s"(fb_word) : "s"(entry), "s"(ws + PROJ_WS_FLAG) : "memory");
+    for (int i = tid; i < LY::total / 16; i += PL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rec), "+s"(fb_word) :: "memory");
+    const bool fallback = fb_word != 0;
+#ifdef PROJ_STAMPS
+    const unsigned long long st_ta = __builtin_amdgcn_s_memtime();             // (after the record has arrived)
+#endif
+    if (tile == 0 && tid == 0) {
+        ws[PROJ_WS_DIRTY] = fallback ? (int)(unsigned)(plane_floats & 0xffffffffll) : 0;
+        ws[PROJ_WS_DIRTY + 1] = fallback ? (int)(plane_floats >> 32) : 0;
+    }
+    const ProjPlanes pl = proj_planes<DEPTH, false>(src, b, g.h, g.w);
+    __syncthreads();
+    if (tid < 7) entry[tid] = 0;                            // the record is in registers: empty for the next call
+    if (fallback) {
+        pull_fallback<DEPTH, false, PL_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
+        return;
+    }
+
+    const int e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3], e4 = rec[4], e5 = rec[5], e6 = rec[6];
+    const int ux0 = 32767 - e0, uy0 = 32767 - e1;
+    const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
+    int ef = 0, ec = 0;                                     // (see proj_pull: scales and weight classes)
+    (void)frexpf(__int_as_float(e4), &ef);
+    if constexpr (DEPTH) (void)frexpf(__int_as_float(e5), &ec);
+    const int emax = (e5 >> 23) & 0xff, emin = e6 ? ((PROJ_INV_BITS - e6) >> 23) & 0xff : emax;
+    const int ncls = DEPTH ? min(4, max(0, emax - emin) / PROJ_CLS_BITS + 1) : 1;
+
+    // one interval per axis: valid target and inside the grid (columns ox0 - 1 .. ox0 + 63, rows oy0 - 1 .. oy0 + 15)
+    const float lox = (float)max(ox0 - 1, 0), loy = (float)max(oy0 - 1, 0);
+    const float hix = fminf((float)(g.w - 1), __uint_as_float(__float_as_uint((float)(ox0 + PROJ_TW)) - 1u));
+    const float hiy = fminf((float)(g.h - 1), __uint_as_float(__float_as_uint((float)(oy0 + PROJ_TH)) - 1u));
+    const unsigned lxb = __float_as_uint(lox), lyb = __float_as_uint(loy);
+    const unsigned spx = __float_as_uint(hix) - lxb, spy = __float_as_uint(hiy) - lyb;
+    // byte address of value cell (T, L) = (T * P + L) * 8 + cell0; count cell: (T * PC + L) * CB + cellc (depth: same pitch,
+    // same size: the value cell's address + an immediate)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lbase;
+    const unsigned cell0 = lds0 - 8u * (unsigned)((oy0 - 1) * P + (ox0 - 1));
+    const unsigned cellc = lds0 + LY::vplane - (unsigned)LY::CB * (unsigned)((oy0 - 1) * PC + (ox0 - 1));
+
+    const int q = lane & 15, rw = lane >> 4;
+    const int xq = ox0 + 4 * q;
+    const bool edge_x = ox0 + PROJ_TW >= g.w, edge_y = oy0 + PROJ_TH >= g.h;     // the tile touches the frame's last column / row
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)(count + (int64_t)b * cb), 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
+
+    // the 2x2 sums of one pass for the lane's four cells: lo / hi halves of the value cells; count cells: clo = weight sum
+    // (depth), chi = addends
+    auto sums4 = [&](int it, unsigned (&vlo)[4], int (&vhi)[4], unsigned (&clo)[4], int (&chi)[4]) {
+        const int yl = it * 4 * PL_NW + wave * 4 + rw;
+        unsigned l0[5], l1[5], h0[5], h1[5], m0[5], m1[5], n0[5], n1[5];
+        auto row_v = [&](int r, unsigned (&lo)[5], unsigned (&hi)[5]) {
+            const char* pr = lbase + ((yl + r) * P + 4 * q) * 8;
+            const uint4 a = *reinterpret_cast<const uint4*>(pr), c = *reinterpret_cast<const uint4*>(pr + 16);
+            const uint2 e = *reinterpret_cast<const uint2*>(pr + 32);
+            lo[0] = a.x; hi[0] = a.y; lo[1] = a.z; hi[1] = a.w; lo[2] = c.x; hi[2] = c.y; lo[3] = c.z; hi[3] = c.w; lo[4] = e.x; hi[4] = e.y;
+        };
+        auto row_c = [&](int r, unsigned (&w)[5], unsigned (&n)[5]) {
+            if constexpr (DEPTH) {
+                const char* pr = lbase + LY::vplane + ((yl + r) * PC + 4 * q) * 8;
+                const uint4 a = *reinterpret_cast<const uint4*>(pr), c = *reinterpret_cast<const uint4*>(pr + 16);
+                const uint2 e = *reinterpret_cast<const uint2*>(pr + 32);
+                w[0] = a.x; n[0] = a.y; w[1] = a.z; n[1] = a.w; w[2] = c.x; n[2] = c.y; w[3] = c.z; n[3] = c.w; w[4] = e.x; n[4] = e.y;
+            } else {
+                const char* pr = lbase + LY::vplane + ((yl + r) * PC + 4 * q) * 4;
+                const uint4 a = *reinterpret_cast<const uint4*>(pr);
+                n[0] = a.x; n[1] = a.y; n[2] = a.z; n[3] = a.w; n[4] = *reinterpret_cast<const unsigned*>(pr + 16);
 #pragma unroll
-        for (int r = 0; r < PROJ_TH; ++r) colbits |= ((s_rowbits[r * 2 + (tid >> 5)] >> (tid & 31)) & 1u) << r;
-        unsigned short* half = reinterpret_cast<unsigned short*>(bits + g.colmap) + ((int64_t)(b * g.w + ox0 + tid) * g.cmw) * 2;
-        half[tyi] = (unsigned short)colbits;
-        if (tyi == g.tiles_y - 1)
-            for (int k = tyi + 1; k < 2 * g.cmw; ++k) half[k] = 0;
+                for (int k = 0; k < 5; ++k) w[k] = 0u;
+            }
+        };
+        row_v(0, l0, h0); row_v(1, l1, h1); row_c(0, m0, n0); row_c(1, m1, n1);
+        if (edge_y && oy0 + yl == g.h - 1) {                // B == T: the row below adds twice
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { l1[k] += l1[k]; h1[k] += h1[k]; m1[k] += m1[k]; n1[k] += n1[k]; }
+        }
+        unsigned sl[5], sh[5], sm[5], sn[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { sl[k] = l0[k] + l1[k]; sh[k] = h0[k] + h1[k]; sm[k] = m0[k] + m1[k]; sn[k] = n0[k] + n1[k]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vlo[j] = sl[j] + sl[j + 1]; vhi[j] = (int)(sh[j] + sh[j + 1]);
+            clo[j] = sm[j] + sm[j + 1]; chi[j] = (int)(sn[j] + sn[j + 1]);
+        }
+        if (edge_x) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (xq + j == g.w - 1) { vlo[j] += sl[j + 1]; vhi[j] += (int)sh[j + 1]; clo[j] += sm[j + 1]; chi[j] += (int)sn[j + 1]; }   // R == L
+        }
+    };
+
+    // one weight class into the grid: every source pixel of the rectangle, once, at its top-left target
+    auto accumulate = [&](int cls, int kv, int kc) {
+        constexpr int CH = PL_CH;
+        const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);        // exact powers of two (the value addend is MINUS the flow)
+        const int ux0a = ux0 & ~3;                                          // quads start at multiples of four pixels
+#if PROJ_DEV_SKIP == 1      // (development: timing of the kernel without its source walk)
+        const int nq = 0;
+#else
+        const int nq = uh > 0 ? (ux0 + uw - 1 - ux0a) / 4 + 1 : 0;          // quads per row
+#endif
+        for (int cs = 0; cs < nq; cs += 64) {
+            // a strip of up to 64 quads; a narrower one packs 64 / width rows into a wave instruction
+            const int width = min(64, nq - cs), rpi = 64 / width;
+            const int lr = lane / width, lc = lane - lr * width;
+            const int px = ux0a + 4 * (cs + lc);
+            const int step = PL_NW * rpi;
+            const int vo = (lr * src.fh + px) * 4, vod = (lr * src.dh + px) * 4;
+            // lanes beyond the strip's rows and pixels beyond the frame's last column: NaN coordinates, never inside
+            float pxf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pxf[j] = (lr < rpi && px + j < g.w) ? (float)(px + j) : __int_as_float(0x7fc00000);
+            float yf = (float)(uy0 + wave * rpi + lr);
+            const float ystep = (float)step;
+            for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
+                proj_v4f qx[CH], qy[CH], qd[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    // (rows of the frame below the rectangle cannot reach the tile, rows below the frame read 0 and sit at
+                    //  y > h - 1: both fail the interval test)
+                    qx[k] = qy[k] = qd[k] = proj_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (row0 + k * step < uh && PROJ_DEV_SKIP != 4) {       // (wave-uniform)
+                        const int yu = uy0 + row0 + k * step;
+                        qx[k] = buf_f32x4(pl.f0, vo, yu * src.fh * 4);
+                        qy[k] = buf_f32x4(pl.f1, vo, yu * src.fh * 4);
+                        if constexpr (DEPTH) qd[k] = buf_f32x4(pl.d, vod, yu * src.dh * 4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    if (row0 + k * step < uh) {                             // (wave-uniform)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float fx = qx[k][j], fy = qy[k][j];
+                            const float x2 = pxf[j] + fx, y2 = yf + fy;                      // (:66-67)
+                            bool hit = (__float_as_uint(x2) - lxb) <= spx && (__float_as_uint(y2) - lyb) <= spy;
+                            float d = 1.0f;
+                            if constexpr (DEPTH) {
+                                d = qd[k][j];
+                                if (ncls > 1) {
+                                    const int delta = emax - ((__float_as_int(d) >> 23) & 0xff);
+                                    const int mine = min((delta >= PROJ_CLS_BITS ? 1 : 0) + (delta >= 2 * PROJ_CLS_BITS ? 1 : 0) + (delta >= 3 * PROJ_CLS_BITS ? 1 : 0), ncls - 1);
+                                    hit = hit && mine == cls;
+                                }
+                            }
+#if PROJ_DEV_SKIP == 3
+                            hit = hit && sv == 12345.0f;
+#endif
+                            if (hit) {
+                                const int L = (int)x2, T = (int)y2;
+                                const unsigned a = (unsigned)(__mul24(T, P) + L) * 8u + cell0;
+                                const float ax = DEPTH ? d * fx : fx, ay = DEPTH ? d * fy : fy;  // (:75-88; depth :74-91)
+                                const unsigned X = (unsigned)__float2int_rn(ax * sv), Y = (unsigned)(__float2int_rn(ay * sv) + PL_BIAS);
+                                __hip_atomic_fetch_add((pl_lds64_t)a, ((unsigned long long)X << 32) | Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if constexpr (DEPTH) {
+                                    const unsigned Wc = (unsigned)(__float2int_rn(d * scn) + PL_BIAS);
+                                    __hip_atomic_fetch_add((pl_lds64_t)(a + (cellc - cell0)), (1ull << 32) | Wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                } else {
+                                    const unsigned ac = (unsigned)(__mul24(T, PC) + L) * 4u + cellc;
+                                    __hip_atomic_fetch_add((pl_lds32_t)ac, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                        }
+                    }
+                    yf += ystep;
+                }
+            }
+        }
+    };
+
+    int shift = 0;                                          // coarser scale of the second try
+    for (int attempt = 0;; ++attempt) {
+        float resx[PL_EPI][4], resy[PL_EPI][4], resc[PL_EPI][4];
+        int nres[PL_EPI][4];
+        int nmax = 0, kv = 0;
+        for (int cls = 0; cls < ncls; ++cls) {
+            if (cls > 0) {
+                __syncthreads();                                // every lane has the previous class's sums
+                for (int i = tid; i < LY::planes / 16; i += PL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+            }
+            // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
+            const int kc = max(-100, min(100, PROJ_ADD_BITS - (ec - PROJ_CLS_BITS * cls))) - shift;
+            kv = max(-100, min(100, PROJ_ADD_BITS - (ef + ec - PROJ_CLS_BITS * cls))) - shift;
+            accumulate(cls, kv, kc);
+#ifdef PROJ_STAMPS
+            if (!attempt && !cls) st_t1 = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < PL_EPI; ++it) {
+                unsigned vlo[4], clo[4];
+                int vhi[4], chi[4];
+                sums4(it, vlo, vhi, clo, chi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = chi[j];                       // addends of the cell (cells outside the frame: none)
+                    nmax = max(nmax, n);
+                    const int Y = (int)(vlo[j] - ((unsigned)n << PROJ_ADD_BITS));
+                    const float fxs = (float)vhi[j], fys = (float)Y;
+                    if constexpr (DEPTH) {
+                        const int Wt = (int)(clo[j] - ((unsigned)n << PROJ_ADD_BITS));
+                        const float px_ = ldexpf(fxs, -kv), py_ = ldexpf(fys, -kv), pc_ = ldexpf((float)Wt, -kc);
+                        if (cls == 0) { resx[it][j] = px_; resy[it][j] = py_; resc[it][j] = pc_; }
+                        else { resx[it][j] += px_; resy[it][j] += py_; resc[it][j] += pc_; }
+                    } else {
+                        resx[it][j] = fxs; resy[it][j] = fys; nres[it][j] = n;
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(nmax > PROJ_ADD_CELL) != 0ull) {
+            nmax = wave_max_i32(nmax);
+            if (lane == 0) atomicMax(&s_misc[0], nmax);
+        }
+
+        // normalise (flowprojection_cuda_kernel.cu:129-134), write the tile once, 16 bytes per lane; leave the bitmaps of
+        // "count != 0" for the hole filler
+        int holes = 0, negs = 0;
+        const float unit = ldexpf(1.0f, kv);                    // FlowProjection: the sums are in units of 2^-kv
+#pragma unroll
+        for (int it = 0; it < PL_EPI; ++it) {
+            const int yl = it * 4 * PL_NW + wave * 4 + rw, y = oy0 + yl;
+            float vxa[4], vya[4], ca[4];
+            unsigned nzb = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool inside = xq + j < g.w && y < g.h;
+                float c, vx, vy;
+                if constexpr (DEPTH) {
+                    c = resc[it][j]; vx = resx[it][j]; vy = resy[it][j];
+                    if (c > 0.0f) { vx /= c; vy /= c; }
+                    if (inside && c < 0.0f) negs += 1;
+                } else {
+                    c = (float)nres[it][j];
+                    const float dd = fmaxf(c, 1.0f) * unit;     // sums / (count * 2^kv); no addends: zero sums
+                    const float r = pl_rcp(dd);
+                    vx = pl_div(resx[it][j], dd, r); vy = pl_div(resy[it][j], dd, r);
+                }
+                vxa[j] = vx; vya[j] = vy; ca[j] = c;
+                if (inside && c != 0.0f) nzb |= 1u << j;
+                if (inside && c <= 0.0f) holes += 1;
+            }
+            if (nzb) atomicOr(&s_rowbits[yl * 2 + (q >> 3)], nzb << ((q & 7) * 4));
+            if (y < g.h) {
+                const int so0 = (oy0 + it * 4 * PL_NW + wave * 4) * oh * 4, soc = (oy0 + it * 4 * PL_NW + wave * 4) * ch * 4;
+                const int vo = (rw * oh + xq) * 4, voc = (rw * ch + xq) * 4;
+                if (xq + 3 < g.w) {
+                    const proj_v4i vx4 = {__float_as_int(vxa[0]), __float_as_int(vxa[1]), __float_as_int(vxa[2]), __float_as_int(vxa[3])};
+                    const proj_v4i vy4 = {__float_as_int(vya[0]), __float_as_int(vya[1]), __float_as_int(vya[2]), __float_as_int(vya[3])};
+                    const proj_v4i c4 = {__float_as_int(ca[0]), __float_as_int(ca[1]), __float_as_int(ca[2]), __float_as_int(ca[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(vx4, ro0, vo, so0, PROJ_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(vy4, ro1, vo, so0, PROJ_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(c4, rcn, voc, soc, PROJ_ST_AUX);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (xq + j < g.w) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(vxa[j]), ro0, vo + 4 * j, so0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(vya[j]), ro1, vo + 4 * j, so0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ca[j]), rcn, voc + 4 * j, soc, 0);
+                        }
+                }
+            }
+        }
+        if (holes) atomicAdd(&s_misc[1], holes);
+        if (negs) atomicAdd(&s_misc[2], negs);
+#ifdef PROJ_STAMPS
+        if (!attempt) st_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+        const int busiest = s_misc[0];
+        if (busiest <= PROJ_ADD_CELL || attempt) break;
+        // a cell took more addends than fit beside it: everything once more, with addends small enough for the busiest cell
+        // (this thread's stores are overwritten in program order)
+        shift = (32 - __clz(busiest - 1)) - 5;                  // ceil(log2(busiest)) - log2(32)
+        __syncthreads();                                        // every thread has read the counter
+        for (int i = tid; i < LY::total / 16; i += PL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
     }
-    // the tile's word for K2: 0 = no holes, 1 = holes, 3 = holes and negative counts (non-zero, yet holes: K2 then
-    // reads the counts).  (A list of the tiles with holes, appended with one atomic per tile, costs ~12 ns per tile
-    // on its counter -- measured: 24 us more on a rough field where most tiles have holes.)
-    if (tid == 0) ws[g.off_list + tile] = s_misc[1] ? (s_misc[2] ? 3 : 1) : 0;
+    pull_bitmaps<PL_THREADS>(g, ws, bits, s_rowbits, s_misc, b, txi, tyi, ox0, oy0, tile, tid);
 #ifdef PROJ_STAMPS
     if (tid == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(ws + g.off_list + g.ntiles + (g.ntiles & 1)) + (int64_t)tile * 8;
@@ -879,7 +1314,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     const bool fallback = proj_dirty_floats(ws) != 0;
     // one workgroup per tile; K1 has left a word per tile: 0 = no holes (most tiles: the workgroup leaves at once),
     // 1 = holes, 3 = holes and negative counts (non-zero, yet holes: the counts are read then)
-    const int tile = blockIdx.x;
+    const int tile = band_item(blockIdx.x, gridDim.x);
     const int tflag = ws[g.off_list + tile];
     if (tile == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;               // K0 of the next call starts afresh
     if (!fallback && (!fillhole || tflag == 0)) return;
@@ -1140,6 +1575,12 @@ static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, fl
     // 16-byte stores need 16-byte aligned rows
     const int vec_ok = ((uintptr_t)out % 16 == 0 && (uintptr_t)count % 16 == 0 && s1.b % 4 == 0 && s1.c % 4 == 0 && s1.h % 4 == 0 &&
                         sc.b % 4 == 0 && sc.h % 4 == 0) ? 1 : 0;
+#ifndef PROJ_NO_LEAN
+    if (vec_in && vec_ok && g.tiles_y <= 65535 && batch <= 65535)
+        hipLaunchKernelGGL((proj_pull_lean<DEPTH>), PROJ_BANDS ? dim3(g.ntiles) : dim3(g.tiles_x, g.tiles_y, batch), dim3(PL_THREADS), 0, st, src, count, out, g,
+                           (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
+    else
+#endif
     if (vec_in)
         hipLaunchKernelGGL((proj_pull<DEPTH, false, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
