@@ -1283,8 +1283,9 @@ __device__ __forceinline__ ProjScan proj_walk_plain(const float* __restrict__ cn
     return r;
 }
 
-#define PROJ_FIN_THREADS 1024
-#define PROJ_LINE_CHUNKS 2          // bitmap lines of up to 128 words (4096 pixels) are searched in registers
+#define PROJ_FIN_THREADS 256        // a wave = four rows of the tile
+#define PROJ_FIN_ROWS (PROJ_TH / (PROJ_FIN_THREADS / 64))
+#define PROJ_LINE_CHUNKS 2          // row bitmap lines of up to 128 words (4096 pixels) are searched in registers
 
 // nearest non-zero word strictly below / above word j of a line whose non-zero words are flagged in m[]; -1: none
 __device__ __forceinline__ int mask_prev(const unsigned long long* m, int j) {
@@ -1308,43 +1309,53 @@ __device__ __forceinline__ int mask_next(const unsigned long long* m, int j) {
     return found;
 }
 
+// Round 3: a tile is a 256-thread workgroup (lane = column, a wave = four rows) whose state words come through the
+// scalar cache, so a tile without holes costs one scalar load; a tile with holes makes TWO rounds of vector loads --
+// the bitmap words of its four rows and three words of its column (own, previous, next: a column's nearest covered
+// cell further than 32 rows away, rare, walks the line), then the counts and flows of the cells found -- both rounds
+// issued for the wave's four rows together.  (Round 2: 1024 threads, a wave per row, the whole column line per lane:
+// 11.4 us per call at 1080p, of which ~5 are the launch and the wait for K1's writes.)
 __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
     int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
-    const bool fallback = proj_dirty_floats(ws) != 0;
-    // one workgroup per tile; K1 has left a word per tile: 0 = no holes (most tiles: the workgroup leaves at once),
-    // 1 = holes, 3 = holes and negative counts (non-zero, yet holes: the counts are read then)
     const int tile = band_item(blockIdx.x, gridDim.x);
-    const int tflag = ws[g.off_list + tile];
+    // header words [2], [3] (the fallback's dirty extent) and the tile's word from K1 (0 = no holes, 1 = holes, 3 = holes
+    // and negative counts: non-zero, yet holes -- the counts are read then)
+    long long dirty;
+    int tflag;
+    asm volatile("s_load_dwordx2 %0, %2, 0x8\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(dirty), "=&s"(tflag) : "s"(ws), "s"(ws + g.off_list + tile) : "memory");
+    const bool fallback = dirty != 0;
     if (tile == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;               // K0 of the next call starts afresh
     if (!fallback && (!fillhole || tflag == 0)) return;
     const int per_img = g.tiles_x * g.tiles_y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;            // wave = row of the tile
-    const bool generic = g.rmw > 64 * PROJ_LINE_CHUNKS || g.cmw > 64 * PROJ_LINE_CHUNKS;
-    {
-        const bool negatives = !fallback && (tflag & 2) != 0;
-        const int b = tile / per_img;
-        const int trem = tile - b * per_img;
-        const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
-        const int x = txi * PROJ_TW + lane, y = tyi * PROJ_TH + wave;
-        const bool inside = x < g.w && y < g.h;
-        float* o0 = out + (int64_t)b * s1.b;
-        float* o1 = o0 + s1.c;
-        const int64_t row = (int64_t)y * s1.h;
-        if (fallback) {
-            if (!inside) return;
-            // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
-            const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
-            const float* p0 = planes + (int64_t)b * g.h * g.w;
-            const float* p1 = p0 + npx;
-            const float* pc = p1 + npx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool generic = g.rmw > 64 * PROJ_LINE_CHUNKS;
+    const bool negatives = !fallback && (tflag & 2) != 0;
+    const int b = tile / per_img;
+    const int trem = tile - b * per_img;
+    const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
+    const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH + wave * PROJ_FIN_ROWS;
+    float* o0 = out + (int64_t)b * s1.b;
+    float* o1 = o0 + s1.c;
+    if (fallback) {
+        // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
+        if (x >= g.w) return;
+        const int64_t npx = (int64_t)(g.ntiles / per_img) * g.h * g.w;
+        const float* p0 = planes + (int64_t)b * g.h * g.w;
+        const float* p1 = p0 + npx;
+        const float* pc = p1 + npx;
+        for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+            const int y = y0 + k;
+            if (y >= g.h) break;
+            const int64_t row = (int64_t)y * s1.h;
             const int64_t me = (int64_t)y * g.w + x;
             const float c = pc[me];
             count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
             if (c > 0.0f) {
                 o0[row + x] = p0[me] / c;
                 o1[row + x] = p1[me] / c;
-                return;
+                continue;
             }
             float v0 = 0.0f, v1 = 0.0f;
             if (fillhole) {
@@ -1367,84 +1378,101 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
             }
             o0[row + x] = v0;
             o1[row + x] = v1;
-            return;
         }
-        const float* cn = count + (int64_t)b * sc.b;
-        const int* rl = bits + g.rowmap + (b * g.h + min(y, g.h - 1)) * g.rmw;
-        const int* cl = bits + g.colmap + (b * g.w + min(x, g.w - 1)) * g.cmw;
-        int xl, xr, yu, yd;
-        if (generic) {
-            if (!(inside && cn[(int64_t)y * sc.h + x] <= 0.0f)) return;
-            xl = proj_bit_walk(rl, x, g.w, -1); xr = proj_bit_walk(rl, x, g.w, +1);
-            yu = proj_bit_walk(cl, y, g.h, -1); yd = proj_bit_walk(cl, y, g.h, +1);
-        } else {
-            // ---- one round of loads: the row's line (lane i = word 64 c + i), this lane's column line (16-byte
-            //      loads, reduced to "which words are non-zero") and its own column word with the two beside it
-            unsigned rw[PROJ_LINE_CHUNKS];
-            unsigned long long rm[PROJ_LINE_CHUNKS], cm[PROJ_LINE_CHUNKS];
+        return;
+    }
+    const float* cn = count + (int64_t)b * sc.b;
+    const int xc = min(x, g.w - 1);
+    const int* cl = bits + g.colmap + (b * g.w + xc) * g.cmw;
+    int xl[PROJ_FIN_ROWS], xr[PROJ_FIN_ROWS], yu[PROJ_FIN_ROWS], yd[PROJ_FIN_ROWS];
+    bool hole[PROJ_FIN_ROWS];
+    if (generic) {
 #pragma unroll
-            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rw[c] = (64 * c + lane < g.rmw) ? (unsigned)rl[64 * c + lane] : 0u;
-            const int i = y >> 5, ib = y & 31, cwords = g.cmw;
-            const unsigned cown = (unsigned)cl[i], cprev = i > 0 ? (unsigned)cl[i - 1] : 0u, cnext = i + 1 < cwords ? (unsigned)cl[i + 1] : 0u;
-            const float cme = (negatives && inside) ? cn[(int64_t)y * sc.h + x] : 0.0f;
-            {
-                const int4* cl4 = reinterpret_cast<const int4*>(cl);
-                const int groups = cwords / 4;
-#pragma unroll
-                for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) {
-                    unsigned long long m = 0ull;
-#pragma unroll 4
-                    for (int k = 16 * c; k < min(groups, 16 * c + 16); ++k) {
-                        const int4 q = cl4[k];
-                        const unsigned long long nib = (q.x ? 1ull : 0ull) | (q.y ? 2ull : 0ull) | (q.z ? 4ull : 0ull) | (q.w ? 8ull : 0ull);
-                        m |= nib << ((4 * k) & 63);
-                    }
-                    cm[c] = m;
-                }
+        for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+            const int y = y0 + k;
+            hole[k] = x < g.w && y < g.h && cn[(int64_t)y * sc.h + x] <= 0.0f;
+            xl[k] = xr[k] = yu[k] = yd[k] = -1;
+            if (hole[k]) {
+                const int* rl = bits + g.rowmap + (b * g.h + y) * g.rmw;
+                xl[k] = proj_bit_walk(rl, x, g.w, -1); xr[k] = proj_bit_walk(rl, x, g.w, +1);
+                yu[k] = proj_bit_walk(cl, y, g.h, -1); yd[k] = proj_bit_walk(cl, y, g.h, +1);
             }
+        }
+    } else {
+        // ---- round one: the rows' lines (lane i = word 64 c + i), this lane's column words, and with negative counts its cells
+        const int i = y0 >> 5;                                              // the column word of the tile's rows
+        unsigned rwd[PROJ_FIN_ROWS][PROJ_LINE_CHUNKS];
+        float cme[PROJ_FIN_ROWS];
 #pragma unroll
-            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rm[c] = __ballot(rw[c] != 0u);
-            const int j = x >> 5, jb = x & 31;
+        for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+            const int* rl = bits + g.rowmap + (b * g.h + min(y0 + k, g.h - 1)) * g.rmw;
+#pragma unroll
+            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rwd[k][c] = (64 * c + lane < g.rmw) ? (unsigned)rl[64 * c + lane] : 0u;
+            cme[k] = (negatives && x < g.w && y0 + k < g.h) ? cn[(int64_t)(y0 + k) * sc.h + x] : 0.0f;
+        }
+        const int cwords = (g.h + 31) >> 5;
+        const unsigned cown = (unsigned)cl[i], cprev = i > 0 ? (unsigned)cl[i - 1] : 0u, cnext = i + 1 < cwords ? (unsigned)cl[i + 1] : 0u;
+        const int j = x >> 5, jb = x & 31;
+#pragma unroll
+        for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+            const int y = y0 + k;
+            unsigned long long rm[PROJ_LINE_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) rm[c] = __ballot(rwd[k][c] != 0u);
             const int jl = mask_prev(rm, j), jr = mask_next(rm, j);
             // the words themselves come from the lanes that hold them
             unsigned own = 0u, wl = 0u, wr = 0u;
 #pragma unroll
             for (int c = 0; c < PROJ_LINE_CHUNKS; ++c) {
-                const unsigned a = (unsigned)__shfl((int)rw[c], j & 63), l2 = (unsigned)__shfl((int)rw[c], jl & 63), r2 = (unsigned)__shfl((int)rw[c], jr & 63);
+                const unsigned a = (unsigned)__shfl((int)rwd[k][c], j & 63), l2 = (unsigned)__shfl((int)rwd[k][c], jl & 63), r2 = (unsigned)__shfl((int)rwd[k][c], jr & 63);
                 if ((j >> 6) == c) own = a;
                 if (jl >= 0 && (jl >> 6) == c) wl = l2;
                 if (jr >= 0 && (jr >> 6) == c) wr = r2;
             }
             // a hole: its bit is clear -- or, in a tile that holds negative counts, its count is not positive
-            const bool hole = inside && (negatives ? cme <= 0.0f : ((own >> jb) & 1u) == 0u);
-            if (!hole) return;
+            hole[k] = x < g.w && y < g.h && (negatives ? cme[k] <= 0.0f : ((own >> jb) & 1u) == 0u);
             const unsigned below = own & ((1u << jb) - 1u), above = jb == 31 ? 0u : own & ~((2u << jb) - 1u);
-            xl = below ? j * 32 + 31 - __clz(below) : jl >= 0 ? jl * 32 + 31 - __clz(wl) : -1;
-            xr = above ? j * 32 + __ffs((int)above) - 1 : jr >= 0 ? jr * 32 + __ffs((int)wr) - 1 : -1;
-            const int iu = mask_prev(cm, i), id = mask_next(cm, i);
-            const unsigned cu = iu < 0 ? 0u : iu == i - 1 ? cprev : (unsigned)cl[iu];
-            const unsigned cd = id < 0 ? 0u : id == i + 1 ? cnext : (unsigned)cl[id];
+            xl[k] = below ? j * 32 + 31 - __clz(below) : jl >= 0 ? jl * 32 + 31 - __clz(wl) : -1;
+            xr[k] = above ? j * 32 + __ffs((int)above) - 1 : jr >= 0 ? jr * 32 + __ffs((int)wr) - 1 : -1;
+            const int ib = y & 31;
             const unsigned cbelow = cown & ((1u << ib) - 1u), cabove = ib == 31 ? 0u : cown & ~((2u << ib) - 1u);
-            yu = cbelow ? i * 32 + 31 - __clz(cbelow) : iu >= 0 ? iu * 32 + 31 - __clz(cu) : -1;
-            yd = cabove ? i * 32 + __ffs((int)cabove) - 1 : id >= 0 ? id * 32 + __ffs((int)cd) - 1 : -1;
+            yu[k] = cbelow ? i * 32 + 31 - __clz(cbelow) : cprev ? (i - 1) * 32 + 31 - __clz(cprev) : -2;
+            yd[k] = cabove ? i * 32 + __ffs((int)cabove) - 1 : cnext ? (i + 1) * 32 + __ffs((int)cnext) - 1 : -2;
+            // not within the three words: walk the rest of the line (32 and more uncovered rows on end)
+            if (hole[k] && yu[k] == -2) yu[k] = i > 1 ? proj_bit_walk(cl, (i - 1) * 32, g.h, -1) : -1;
+            if (hole[k] && yd[k] == -2) yd[k] = i + 2 < cwords ? proj_bit_walk(cl, (i + 1) * 32 + 31, g.h, +1) : -1;
         }
-        // a walk that found nothing contributes weight 0; its position only has to be valid
-        ProjScan l, rr, u, d;
-        l.pos = xl < 0 ? x : xl; rr.pos = xr < 0 ? x : xr; u.pos = yu < 0 ? y : yu; d.pos = yd < 0 ? y : yd;
-        l.cnt = xl < 0 ? 0.0f : cn[(int64_t)y * sc.h + xl];
-        rr.cnt = xr < 0 ? 0.0f : cn[(int64_t)y * sc.h + xr];
-        u.cnt = yu < 0 ? 0.0f : cn[(int64_t)yu * sc.h + x];
-        d.cnt = yd < 0 ? 0.0f : cn[(int64_t)yd * sc.h + x];
-        const float a0 = o0[row + l.pos], b0 = o0[row + rr.pos], c0 = o0[(int64_t)u.pos * s1.h + x], d0 = o0[(int64_t)d.pos * s1.h + x];
-        const float a1 = o1[row + l.pos], b1 = o1[row + rr.pos], c1 = o1[(int64_t)u.pos * s1.h + x], d1 = o1[(int64_t)d.pos * s1.h + x];
-        if (l.cnt + rr.cnt + u.cnt + d.cnt <= 0.0f) return;
-        const float lt = (l.cnt > 0.0f) ? 1.0f : 0.0f;
-        const float rt = (rr.cnt > 0.0f) ? 1.0f : 0.0f;
-        const float ut = (u.cnt > 0.0f) ? 1.0f : 0.0f;
-        const float dt = (d.cnt > 0.0f) ? 1.0f : 0.0f;
+    }
+    // ---- round two: the cells found.  A walk that found nothing contributes weight 0; its position only has to be valid
+    float lc[PROJ_FIN_ROWS], rc[PROJ_FIN_ROWS], uc[PROJ_FIN_ROWS], dc[PROJ_FIN_ROWS];
+    float a0[PROJ_FIN_ROWS], b0[PROJ_FIN_ROWS], c0[PROJ_FIN_ROWS], d0[PROJ_FIN_ROWS], a1[PROJ_FIN_ROWS], b1[PROJ_FIN_ROWS], c1[PROJ_FIN_ROWS], d1[PROJ_FIN_ROWS];
+#pragma unroll
+    for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+        lc[k] = rc[k] = uc[k] = dc[k] = 0.0f;
+        a0[k] = b0[k] = c0[k] = d0[k] = a1[k] = b1[k] = c1[k] = d1[k] = 0.0f;
+        if (hole[k]) {
+            const int y = y0 + k;
+            const int64_t row = (int64_t)y * s1.h, crow = (int64_t)y * sc.h;
+            const int pl_ = xl[k] < 0 ? x : xl[k], pr_ = xr[k] < 0 ? x : xr[k], pu = yu[k] < 0 ? y : yu[k], pd = yd[k] < 0 ? y : yd[k];
+            if (xl[k] >= 0) lc[k] = cn[crow + xl[k]];
+            if (xr[k] >= 0) rc[k] = cn[crow + xr[k]];
+            if (yu[k] >= 0) uc[k] = cn[(int64_t)yu[k] * sc.h + x];
+            if (yd[k] >= 0) dc[k] = cn[(int64_t)yd[k] * sc.h + x];
+            a0[k] = o0[row + pl_]; b0[k] = o0[row + pr_]; c0[k] = o0[(int64_t)pu * s1.h + x]; d0[k] = o0[(int64_t)pd * s1.h + x];
+            a1[k] = o1[row + pl_]; b1[k] = o1[row + pr_]; c1[k] = o1[(int64_t)pu * s1.h + x]; d1[k] = o1[(int64_t)pd * s1.h + x];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PROJ_FIN_ROWS; ++k) {
+        if (!hole[k] || lc[k] + rc[k] + uc[k] + dc[k] <= 0.0f) continue;
+        const float lt = (lc[k] > 0.0f) ? 1.0f : 0.0f;
+        const float rt = (rc[k] > 0.0f) ? 1.0f : 0.0f;
+        const float ut = (uc[k] > 0.0f) ? 1.0f : 0.0f;
+        const float dt = (dc[k] > 0.0f) ? 1.0f : 0.0f;
         const float den = lt + rt + ut + dt;
-        o0[row + x] = (lt * a0 + rt * b0 + ut * c0 + dt * d0) / den;
-        o1[row + x] = (lt * a1 + rt * b1 + ut * c1 + dt * d1) / den;
+        const int64_t row = (int64_t)(y0 + k) * s1.h;
+        o0[row + x] = (lt * a0[k] + rt * b0[k] + ut * c0[k] + dt * d0[k]) / den;
+        o1[row + x] = (lt * a1[k] + rt * b1[k] + ut * c1[k] + dt * d1[k]) / den;
     }
 }
 
