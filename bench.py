@@ -35,7 +35,8 @@ Every native call goes through the C ABI of libvfi_hip.so (ctypes, vfidkr_amd/ca
                     algorithmic), `cold` = every call on a buffer set that has left the 256 MB Infinity Cache
                     (rotation through > 512 MB of sets), `hot` = the same set every call
   cpu_baseline      the CPU oracle (oracle/, a port: kind "port") timed on the host cores on a bounded sample
-                    of the same workload at 1 thread and at all cores, rank 0 at N=1 only
+                    of the same workload (one of the step's six units, every call of it run in full) at 1 thread and at
+                    all cores, rank 0 at N=1 only
 """
 import argparse
 import json
@@ -147,6 +148,14 @@ def run_rank(args):
     import vfidkr_amd  # noqa: F401
     from vfidkr_amd import runner
 
+    if args.stub_step is None:
+        # before the process group: a rank without a device leaves with a message instead of hanging the others in a barrier
+        rank, local_rank, world = runner.dist_env()
+        n = torch.cuda.device_count()
+        # (ranks of an external launcher may share a device, local_rank % n: the one-GPU rehearsal; our own launcher insists on one each)
+        if n < 1 or (os.environ.get("VFI_BENCH_OWN_RANKS") == "1" and n < world):
+            print("bench.py: rank %d: --gpus %d but %d GPU(s) visible" % (rank, max(args.gpus, world), n), file=sys.stderr)
+            return 2
     rank, local_rank, world = runner.init_distributed()
     if args.stub_step is not None:
         return run_stub(args, runner, rank, world)
@@ -323,15 +332,16 @@ def roofline_block(kernel, px, ms, launches, traffic, bytes_per_px=1640.0):
             "avg_launch_ms": round(ms, 4), "launches_timed": launches}
 
 
-def traffic_lookup(h, w, flow_model, direct):
-    """HBM bytes per C=196 launch from the committed rocprofv3 PMC passes -- only for the exact (frame size, flow
-    model, kernel) they were collected on (profiles/README.md says how); anything else has no counter evidence: null."""
+def traffic_lookup(h, w, flow_model, direct, op="fi196"):
+    """HBM bytes per call of `op` (fi196: the C=196 launch; fi_c3; flowproj: all three launches of a call) from the
+    committed rocprofv3 PMC passes -- only for the exact (frame size, flow model, kernel) they were collected on
+    (profiles/README.md says how); anything else has no counter evidence: null."""
     path = os.path.join(ROOT, "profiles", "traffic_by_config.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
         for e in json.load(fh).get("entries", []):
-            if (e.get("h"), e.get("w"), e.get("flow_model"), bool(e.get("direct"))) == (h, w, flow_model, bool(direct)):
+            if (e.get("h"), e.get("w"), e.get("flow_model"), bool(e.get("direct")), e.get("op", "fi196")) == (h, w, flow_model, bool(direct), op):
                 return e.get("hbm_bytes_per_launch")
     return None
 
@@ -385,6 +395,10 @@ def gate_measurement(torch, cabi, S, wl, dev, args, iters=60):
                      "frac_of_8TBps": round(gbytes / (total_ms * 1e-3) / HBM_PEAK_GBS, 4)}
     res["algorithmic_GB"] = round(gbytes, 4)
     res["frac_of_8TBps"] = res["cold"]["frac_of_8TBps"]             # the figure that counts: nothing cache resident
+    # HBM-side bytes per call from the PMC passes under profiles/ (null for a configuration they were not collected on)
+    res["traffic"] = {"fi_c3_bytes_per_call": traffic_lookup(h, w, args.flow_model, args.direct, "fi_c3"),
+                      "flowproj_bytes_per_call": traffic_lookup(h, w, args.flow_model, False, "flowproj"),
+                      "fi_c3_algorithmic_bytes": 96.0 * px, "flowproj_algorithmic_bytes": 20.0 * px}
     return res
 
 
@@ -478,20 +492,18 @@ def shared_window_measurement(torch, cabi, wl, dev, args):
 
 
 def cpu_baseline(torch, cabi, wl, dev, args):
-    """Times the CPU oracle (a port of the reference's arithmetic; the reference has no CPU path) on a bounded
-    sample of one step -- at 1 thread and at every host core, median of 5 runs each -- and scales it to a step;
-    also reports the parity of the GPU result on that sample.  Sample: one (direction, t) unit with the context
-    tensor cut to 16 of its 196 channels (FilterInterpolation's cost is linear in channels, the flow / filter
-    part is in the C=3 call's measurement), and the 5-level correlation of one direction."""
+    """Times the CPU oracle (a port of the reference's arithmetic; the reference has no CPU path) on one (direction, t)
+    unit of the step -- DepthFlowProjection, FilterInterpolation on the frame and on the WHOLE 196-channel context tensor,
+    the 5-level correlation of one direction -- and scales it to a step (6 units + 2 correlation pyramids).  At every
+    host core: median of 5 runs per call (the 196-channel call included: it is 85 % of the step).  At one thread: median
+    of 5 for the short calls, ONE run of the 196-channel call (~11 s).  Also reports the parity of the GPU results on the
+    same inputs, the whole context tensor included."""
     import numpy as np
     from oracle import cpu_oracle as oracle
     ncpu = os.cpu_count() or 1
-    csel = 16
     frame, filt = wl.frames[0].cpu().numpy(), wl.filters[0].cpu().numpy()
     depth, flow = wl.depth[0].cpu().numpy(), wl.flows[0][1].cpu().numpy()
-    ctx_dev = torch.empty((1, csel, wl.h, wl.w), dtype=torch.float32, device=dev)      # fresh dense strides: a channel slice of a
-    ctx_dev.copy_(wl.ctx[0][:, :csel])                                                 # B = 1 tensor keeps the 196-channel batch stride
-    ctx_sel = ctx_dev.cpu().numpy()
+    ctx = wl.ctx[0].cpu().numpy()
     corr_np = [(a.cpu().numpy(), b.cpu().numpy()) for a, b in wl.corr[0]]
     proj, _ = oracle.depthflowproj_fwd(flow, depth, 1)
 
@@ -503,34 +515,30 @@ def cpu_baseline(torch, cabi, wl, dev, args):
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts), r
 
-    def one_config(threads):
+    def one_config(threads, runs196):
         oracle.set_num_threads(threads)
         t_dfp, _ = med(lambda: oracle.depthflowproj_fwd(flow, depth, 1))            # sequential scatter: one thread whatever `threads`
         t_fi3, ref_img = med(lambda: oracle.filterinterp_ori_fwd(frame, proj, filt, fmad=1, nthreads=threads))
-        t_fic, ref_ctx = med(lambda: oracle.filterinterp_ori_fwd(ctx_sel, proj, filt, fmad=1, nthreads=threads))
+        t_fic, ref_ctx = med(lambda: oracle.filterinterp_ori_fwd(ctx, proj, filt, fmad=1, nthreads=threads), runs196)
         t_corr, corr_ref = med(lambda: [oracle.correlation_fwd(a, b, 4, 1, 4, 1, 1, order=0) for a, b in corr_np][-1])
-        # channels scale the per-channel part of the C=16 call: t(C) = t_fixed + C * t_channel, from the C=3 and C=16 runs
-        per_ch = max(0.0, (t_fic - t_fi3) / float(csel - 3))
-        t_fi196 = t_fi3 + per_ch * (196 - 3)
-        step_s = 6 * (t_dfp + t_fi196 + t_fi3) + 2 * t_corr
-        return dict(threads=threads, dfp=t_dfp, fi3=t_fi3, fi16=t_fic, fi196=t_fi196, corr=t_corr, step=step_s), ref_img, ref_ctx, corr_ref
+        step_s = 6 * (t_dfp + t_fic + t_fi3) + 2 * t_corr
+        return dict(threads=threads, dfp=t_dfp, fi3=t_fi3, fi196=t_fic, corr=t_corr, step=step_s), ref_img, ref_ctx, corr_ref
 
-    c1, _, _, _ = one_config(1)
-    cn, ref_img, ref_ctx, corr_ref = one_config(ncpu)
+    c1, _, _, _ = one_config(1, 1)
+    cn, ref_img, ref_ctx, corr_ref = one_config(ncpu, 5)
     base = {"value": round(len(TIMES) / cn["step"], 5), "unit": "frames/s", "cores": ncpu, "kind": "port",
             "value_1_thread": round(len(TIMES) / c1["step"], 5),
-            "sample": "oracle/vfi_oracle.c (C restatement; the reference has no CPU path) at %dx%d, median of 5 runs per call, "
-                      "at 1 thread / %d threads: DepthFlowProjection %.3f / %.3f s (sequential scatter), FilterInterpolation "
-                      "C=3 %.3f / %.3f s, C=16 %.3f / %.3f s -> C=196 extrapolated linearly in channels %.2f / %.2f s, "
-                      "5-level correlation of one direction %.3f / %.3f s; step = 6 x (proj + FI196 + FI3) + 2 x corr = "
-                      "%.1f / %.2f s"
-                      % (wl.h, wl.w, ncpu, c1["dfp"], cn["dfp"], c1["fi3"], cn["fi3"], c1["fi16"], cn["fi16"], c1["fi196"],
-                         cn["fi196"], c1["corr"], cn["corr"], c1["step"], cn["step"])}
+            "sample": "oracle/vfi_oracle.c (C restatement; the reference has no CPU path) at %dx%d, one (direction, t) unit + one "
+                      "correlation pyramid, every call run in full, median of 5 runs (the 1-thread C=196 call: one run), at 1 thread / "
+                      "%d threads: DepthFlowProjection %.3f / %.3f s (sequential scatter), FilterInterpolation C=3 %.3f / %.3f s, "
+                      "C=196 %.2f / %.2f s, 5-level correlation of one direction %.3f / %.3f s; step = 6 x (proj + FI196 + FI3) + "
+                      "2 x corr = %.1f / %.2f s"
+                      % (wl.h, wl.w, ncpu, c1["dfp"], cn["dfp"], c1["fi3"], cn["fi3"], c1["fi196"], cn["fi196"], c1["corr"],
+                         cn["corr"], c1["step"], cn["step"])}
 
-    # parity of the GPU path on the same sample (GPU fed the oracle's projected flow -> exact compare)
+    # parity of the GPU path on the same inputs (GPU fed the oracle's projected flow -> exact compare)
     gproj = torch.tensor(proj, device=dev)
-    out = torch.empty((1, csel, wl.h, wl.w), dtype=torch.float32, device=dev)
-    assert cabi.filterinterp_forward_ori(ctx_dev, gproj, wl.filters[0], out, direct=args.direct) == 0
+    assert cabi.filterinterp_forward_ori(wl.ctx[0], gproj, wl.filters[0], wl.out_ctx, direct=args.direct) == 0
     out3 = torch.empty_like(wl.frames[0])
     assert cabi.filterinterp_forward_ori(wl.frames[0], gproj, wl.filters[0], out3, direct=args.direct) == 0
     cnt = torch.empty_like(wl.count)
@@ -546,7 +554,7 @@ def cpu_baseline(torch, cabi, wl, dev, args):
     psnr = float("inf") if mse == 0 else 20.0 * np.log10(255.0 / np.sqrt(mse))    # demo_MiddleBury.py:370-378
     parity = {"vs": "CPU oracle (fmad=1) on the same inputs",
               "filterinterp_c3_max_abs_err": err3,
-              "filterinterp_ctx_max_abs_err": float(np.abs(out.cpu().numpy() - ref_ctx).max()),
+              "filterinterp_ctx_max_abs_err": float(np.abs(wl.out_ctx.cpu().numpy() - ref_ctx).max()),
               "depthflowproj_max_abs_err": float(np.abs(gp.cpu().numpy() - proj).max()),
               "correlation_max_abs_err": float(np.abs(gcorr.cpu().numpy() - corr_ref).max()),
               "psnr_db_uint8_frame": 99.0 if psnr == float("inf") else round(psnr, 2)}
@@ -559,15 +567,10 @@ def main(argv=None):
     args = parse(argv)
     from vfidkr_amd import runner
     if args.gpus > 1 and not runner.launched_externally():
-        # start the ranks ourselves, before anything here has touched a GPU (device_count does not initialise HIP)
-        if args.stub_step is None:
-            import torch
-            n = torch.cuda.device_count()
-            if n < args.gpus:
-                print("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, n), file=sys.stderr)
-                return 2
+        # start the ranks ourselves; the parent never touches the GPU runtime (not even to count devices: on ROCm that can
+        # open HIP) -- every rank validates its own device and exits 2 with a message, which spawn_ranks passes on
         child = [os.path.abspath(__file__)] + (list(argv) if argv is not None else sys.argv[1:])
-        return runner.spawn_ranks(child, args.gpus)
+        return runner.spawn_ranks(child, args.gpus, extra_env={"VFI_BENCH_OWN_RANKS": "1"})
     return run_rank(args)
 
 
