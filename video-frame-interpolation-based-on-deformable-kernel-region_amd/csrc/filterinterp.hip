@@ -64,13 +64,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
-    const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g2, float* g3,
+    const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g1, float* g2, float* g3,
     int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
-    const float gscale = gradacc_scale(hdr);
+    const GradAccCtx gctx = gradacc_ctx(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     for (int c = 0; c < channel; ++c) {
         const float* p = img + (int64_t)c * s1.c;
         unsigned long long* gp = gimg + (int64_t)c * h * w;
+        float* gfp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c;    // (the fp32 scatter of a call with non-finite inputs)
         const float g = gpx[(int64_t)c * s1.c];
         const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
                               g * (1.0f - alpha) * beta,          g * alpha * beta };
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
                     // image gradient: other pixels hit the same cell -> order-free fixed-point atomic (vfi_common.h).
                     // The filter gradient cell belongs to this thread alone (index is this pixel's own), so a plain
                     // read-modify-write is equivalent to the reference's atomicAdd.
-                    gradacc_add(&gp[(int64_t)clampi(j, 0, h - 1) * w + clampi(i, 0, w - 1)], qg[quad] * fv, gscale);
+                    gradacc_add(gp, gfp, (int64_t)clampi(j, 0, h - 1) * w + clampi(i, 0, w - 1), o, qg[quad] * fv, gctx);
                     gfpx[k] += qg[quad] * pv;
                     acc = fmaf(pv, fv, acc);
                 }
@@ -244,13 +245,13 @@ template <int VARIANT>
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     const float* __restrict__ in4, const float* __restrict__ gout, unsigned long long* __restrict__ acc,
-    const int* __restrict__ hdr, float* g2, float* g3, float* g4,
+    const int* __restrict__ hdr, float* g1, float* g2, float* g3, float* g4,
     int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
-    const float gscale = gradacc_scale(hdr);
+    const GradAccCtx gctx = gradacc_ctx(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     for (int c = 0; c < channel; ++c) {
         const float* p = img + (int64_t)c * s1.c;
         unsigned long long* gp = gimg + (int64_t)c * h * w;
+        float* gfp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c;    // (the fp32 scatter of a call with non-finite inputs)
         const float g = gpx[(int64_t)c * s1.c];
         const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
                               g * (1.0f - alpha) * beta,          g * alpha * beta };
@@ -313,13 +315,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
                 dX = fmaf(phiY, vBR, dX);
                 const int64_t o = (int64_t)cj * w + ci;
                 if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
-                    gradacc_add(&gp[o], qg[quad], gscale);
+                    gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad], gctx);
                     q[quad] = q[quad] + v;
                     gopx[(int64_t)k * ocs] += g * kq[quad] * dY;
                     gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX;
                 } else {
                     const float wgt = fpx[(int64_t)k * s3.c];
-                    gradacc_add(&gp[o], qg[quad] * wgt, gscale);
+                    gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad] * wgt, gctx);
                     gfpx[(int64_t)k * s3.c] += qg[quad] * v;
                     q[quad] = fmaf(v, wgt, q[quad]);
                     gopx[(int64_t)k * ocs] += g * kq[quad] * dY * wgt;
@@ -409,10 +411,10 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
     const int fs = fi_filter_size(filter_channels);
     unsigned long long* acc;
     int* hdr;
-    int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, input3, filter_channels, s3, &acc, &hdr);
     if (err != VFI_OK) return err;
     hipLaunchKernelGGL(fi_backward_ori, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, input3, gradoutput, acc, hdr, gradinput2, gradinput3,
+                       input1, input2, input3, gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3,
                        channel, h, w, fs, s1, s2, s3);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
@@ -495,22 +497,24 @@ extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1,
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* acc;
     int* hdr;
-    const int err = gradacc_begin(st, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    // (the tap weights of the variant without a filter are 1)
+    const int err = gradacc_begin(st, gradoutput, batch, channel, h, w, s1, variant == VFI_DEFOR_NOFILTER ? nullptr : input3,
+                                  filter_size * filter_size, s3, &acc, &hdr);
     if (err != VFI_OK) return err;
     switch (variant) {
     case VFI_DEFOR_OFFSET:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
                            s1, s2, s3, s4);
         break;
     case VFI_DEFOR_REGION:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
                            s1, s2, s3, s4);
         break;
     default:
         hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3, input3,
-                           gradoutput, acc, hdr, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
+                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
                            s1, s2, s3, s3);
         break;
     }

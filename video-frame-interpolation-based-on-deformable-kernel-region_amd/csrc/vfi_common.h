@@ -84,23 +84,43 @@ int fi_channel_groups(int ntiles, int channel, double prologue);
 
 // Deterministic image gradients.  The reference scatters the image gradient of its warping layers with fp32 atomics
 // (filterinterpolation_cuda_kernel.cu:2890-2942, interpolation_cuda_kernel.cu:154-157): the sum depends on the order the
-// atomics arrive in, so two runs differ in the last bits.  Here every addend is scaled by ONE power of two per call
-// (2^36 over the largest |gradoutput| element: 2^10 of headroom for the tap weights, 2^16 addends per cell), rounded to
-// an integer and added with a 64-bit INTEGER atomic into a scratch plane; a last pass converts the exact integer sums
-// to float once and adds them to the caller's (zero-filled) gradient.  Order-free, hence reproducible bit for bit.
-//   host:   gradacc_begin (zeroes the scratch, finds the largest |gradoutput|)  ->  the backward kernel  ->  gradacc_finish
-//   device: gradacc_scale(hdr) once per thread, gradacc_add(cell, addend, scale) per addend; cells are indexed densely
-//           [b][c][y][x] whatever the strides of the gradient tensor.
-__device__ __forceinline__ float gradacc_scale(const int* __restrict__ hdr) {
-    int e = 0;
-    (void)frexpf(__int_as_float(hdr[0]), &e);
-    return ldexpf(1.0f, max(-100, min(100, 36 - e)));
+// atomics arrive in, so two runs differ in the last bits.  Here every addend is scaled by ONE power of two per call,
+// rounded to an integer and added with a 64-bit INTEGER atomic into a scratch plane; a last pass converts the exact
+// integer sums to float once and adds them to the caller's (zero-filled) gradient.  Order-free, hence reproducible bit
+// for bit.  The scale is 2^(62 - ceil(log2(h w)) - eg - ew) with 2^eg > max |gradoutput| and 2^ew > max |tap weight|
+// (the filter tensor; 1 where the weights are bilinear fractions only): an addend is below 2^(62 - ceil(log2(h w))) and
+// even a cell that EVERY pixel of the frame hits stays inside 63 bits -- no combination of finite inputs overflows.
+// Non-finite inputs: the first pass raises a flag when gradoutput or the weights hold a NaN or an infinity, and the
+// kernels then scatter with the reference's own fp32 atomics for that call (NaN / Inf propagate to exactly the cells
+// the reference would poison; the integer path would turn them into finite garbage).
+//   host:   gradacc_begin (zeroes the scratch; largest |gradoutput|, largest |weight|, non-finite flag)  ->  the backward kernel
+//           ->  gradacc_finish
+//   device: gradacc_ctx(hdr) once per thread, gradacc_add(...) per addend; cells are indexed densely [b][c][y][x] whatever
+//           the strides of the gradient tensor.
+// hdr words: [0] bits of max |gradoutput|, [1] non-finite flag, [2] bits of max |weight| (0: none given), [3] ceil(log2(h w))
+struct GradAccCtx { float scale; bool nonfinite; };
+__device__ __forceinline__ int gradacc_exponent(const int* __restrict__ hdr) {
+    int eg = 0, ew = 1;                                     // no weight tensor: |weight| <= 1 < 2^1
+    (void)frexpf(__int_as_float(hdr[0]), &eg);
+    if (hdr[2] != 0) (void)frexpf(__int_as_float(hdr[2]), &ew);
+    return max(-126, min(126, 62 - hdr[3] - eg - max(ew, 1)));
 }
-__device__ __forceinline__ void gradacc_add(unsigned long long* cell, float v, float scale) {
-    atomicAdd(cell, (unsigned long long)__float2ll_rn(v * scale));
+__device__ __forceinline__ GradAccCtx gradacc_ctx(const int* __restrict__ hdr) {
+    GradAccCtx c;
+    c.scale = ldexpf(1.0f, gradacc_exponent(hdr));
+    c.nonfinite = hdr[1] != 0;
+    return c;
 }
+// acc_plane / g_plane: the channel's plane of the dense scratch and of the caller's gradient tensor; di / gi: the cell's
+// index in each
+__device__ __forceinline__ void gradacc_add(unsigned long long* acc_plane, float* g_plane, int64_t di, int64_t gi, float v,
+                                            const GradAccCtx& cx) {
+    if (cx.nonfinite) atomicAdd(&g_plane[gi], v);
+    else atomicAdd(&acc_plane[di], (unsigned long long)__float2ll_rn(v * cx.scale));
+}
+// weights (may be null): a [batch, wchannel, h, w] tensor whose largest |element| bounds the tap weights
 int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
-                  unsigned long long** acc, int** hdr);
+                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr);
 int gradacc_finish(hipStream_t st, const unsigned long long* acc, const int* hdr, float* g1, int batch, int channel, int h, int w,
                    vfi_strides s1);
 

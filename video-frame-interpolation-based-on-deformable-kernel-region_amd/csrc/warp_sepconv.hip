@@ -43,13 +43,13 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_forward(
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
-    unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g2, int channel, int h, int w, vfi_strides s1,
+    unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g1, float* g2, int channel, int h, int w, vfi_strides s1,
     vfi_strides s2) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
-    const float gscale = gradacc_scale(hdr);
+    const GradAccCtx gctx = gradacc_ctx(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
     const float fy = flow[s2.c];
@@ -71,10 +71,11 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
         const float* p = img + (int64_t)c * s1.c;
         unsigned long long* gp = gimg + (int64_t)c * h * w;
         const float g = gpx[(int64_t)c * s1.c];
-        gradacc_add(&gp[aT + L], g * (1.0f - alpha) * (1.0f - beta), gscale);     // (:151-158)
-        gradacc_add(&gp[aT + R], g * alpha * (1.0f - beta), gscale);
-        gradacc_add(&gp[aB + L], g * (1.0f - alpha) * beta, gscale);
-        gradacc_add(&gp[aB + R], g * alpha * beta, gscale);
+        float* gfp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c;    // (the fp32 scatter of a call with non-finite inputs)
+        gradacc_add(gp, gfp, aT + L, oT + L, g * (1.0f - alpha) * (1.0f - beta), gctx);     // (:151-158)
+        gradacc_add(gp, gfp, aT + R, oT + R, g * alpha * (1.0f - beta), gctx);
+        gradacc_add(gp, gfp, aB + L, oB + L, g * (1.0f - alpha) * beta, gctx);
+        gradacc_add(gp, gfp, aB + R, oB + R, g * alpha * beta, gctx);
         const float tl = p[oT + L], tr = p[oT + R], bl = p[oB + L], br = p[oB + R];
         float temp = gam_y * (tr - tl);
         temp = fmaf(1.0f - gam_y, br - bl, temp);
@@ -278,10 +279,11 @@ extern "C" int vfi_interpolation_backward(const float* input1, const float* inpu
         return VFI_ERR_SHAPE;
     unsigned long long* acc;
     int* hdr;
-    const int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, &acc, &hdr);
+    // (the tap weights are bilinear fractions: at most 1)
+    const int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, nullptr, 0, s1, &acc, &hdr);
     if (err != VFI_OK) return err;
     hipLaunchKernelGGL(interp_backward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, gradoutput, acc, hdr, gradinput2, channel, h, w, s1, s2);
+                       input1, input2, gradoutput, acc, hdr, gradinput1, gradinput2, channel, h, w, s1, s2);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }

@@ -52,26 +52,31 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
 }
 
 // ---- deterministic image gradients (vfi_common.h)
+// largest |element| of a [batch, channel, h, w] tensor into hdr[slot] (non-negative floats order like their bits); a NaN or an
+// infinity raises hdr[1]
 __global__ __launch_bounds__(256) void gradacc_max(const float* __restrict__ g, int channel, int h, int w, vfi_strides sg, int64_t n,
-                                                   int* __restrict__ hdr) {
+                                                   int* __restrict__ hdr, int slot, int cells_log2) {
     int m = 0;
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int x = (int)(i % w);
         const int y = (int)((i / w) % h);
         const int c = (int)((i / ((int64_t)w * h)) % channel);
         const int b = (int)(i / ((int64_t)w * h * channel));
-        const float v = fabsf(g[(int64_t)b * sg.b + (int64_t)c * sg.c + (int64_t)y * sg.h + x]);
-        m = max(m, v == v ? __float_as_int(v) : 0);        // non-negative floats order like their bits; NaNs do not count
+        const int bits = __float_as_int(fabsf(g[(int64_t)b * sg.b + (int64_t)c * sg.c + (int64_t)y * sg.h + x]));
+        bad = bad || bits >= 0x7f800000;                    // infinity or NaN
+        m = max(m, bits >= 0x7f800000 ? 0 : bits);
     }
     m = wave_max_i32(m);
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&hdr[0], m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&hdr[slot], m);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&hdr[1], 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slot == 0) hdr[3] = cells_log2;
 }
 
 __global__ __launch_bounds__(256) void gradacc_convert(const unsigned long long* __restrict__ acc, const int* __restrict__ hdr,
                                                        float* __restrict__ g1, int channel, int h, int w, vfi_strides s1, int64_t n) {
-    int e = 0;
-    (void)frexpf(__int_as_float(hdr[0]), &e);
-    const int k = max(-100, min(100, 36 - e));
+    if (hdr[1] != 0) return;                                // the call scattered with fp32 atomics: nothing in the scratch
+    const int k = gradacc_exponent(hdr);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const long long sum = (long long)acc[i];
         if (sum == 0) continue;
@@ -85,15 +90,22 @@ __global__ __launch_bounds__(256) void gradacc_convert(const unsigned long long*
 }
 
 int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
-                  unsigned long long** acc, int** hdr) {
+                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr) {
     const int64_t n = (int64_t)batch * channel * h * w;
     void* p = ws_get(st, WS_GRADACC, (size_t)n * 8 + 256, false, nullptr);
     if (!p) return VFI_ERR_LAUNCH;
     if (hipMemsetAsync(p, 0, (size_t)n * 8 + 256, st) != hipSuccess) return VFI_ERR_LAUNCH;
     *hdr = static_cast<int*>(p);
     *acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 256);
+    int cells_log2 = 0;
+    while (((int64_t)1 << cells_log2) < (int64_t)h * w) ++cells_log2;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(gradacc_max, dim3(blocks), dim3(256), 0, st, gout, channel, h, w, sg, n, *hdr);
+    hipLaunchKernelGGL(gradacc_max, dim3(blocks), dim3(256), 0, st, gout, channel, h, w, sg, n, *hdr, 0, cells_log2);
+    if (weights) {
+        const int64_t nw = (int64_t)batch * wchannel * h * w;
+        const int wblocks = (int)((nw + 255) / 256 < 4096 ? (nw + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gradacc_max, dim3(wblocks), dim3(256), 0, st, weights, wchannel, h, w, sw, nw, *hdr, 2, cells_log2);
+    }
     return launch_status();
 }
 
