@@ -1710,6 +1710,32 @@ def test_filterinterp_multi_flow_1080p(torch_mod, cabi, oracle):
     assert np.array_equal(cpu(pairs[2][0][:, sel]), ref)
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_filterinterp_ctx_all_on_channel_slices(torch_mod, cabi, oracle, B):
+    """fused.FilterInterpolate_ctx_all on channel slices of a larger tensor -- views with the parent's batch stride (for B = 1
+    the stride of a size-1 dimension, which torch leaves arbitrary) whose outputs must keep the view's layout: the three time
+    offsets from one launch per direction == three single calls == the oracle."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import fused
+    rng = np.random.default_rng(77 + B)
+    H, W = 40, 72
+    parent = gpu(torch, rng.standard_normal((B, 12, H, W)).astype(f32))
+    ctx0, ctx2 = parent[:, 2:7], parent[:, 5:10]
+    assert ctx0.stride(0) == 12 * H * W
+    filt = [gpu(torch, rng.random((B, 16, H, W), dtype=f32)) for _ in range(2)]
+    base = [smooth_flow(rng, B, H, W, 4.0) for _ in range(2)]
+    offs = [[gpu(torch, (base[d] * f32(2.0 * t)).astype(f32)) for t in (0.25, 0.5, 0.75)] for d in range(2)]
+    pairs = fused.FilterInterpolate_ctx_all(ctx0, ctx2, offs, filt)
+    for t in range(3):
+        for d, ctx in enumerate((ctx0, ctx2)):
+            assert pairs[t][d].stride() == ctx.stride()
+            single = torch.empty_strided(ctx.shape, ctx.stride(), dtype=ctx.dtype, device=ctx.device)
+            assert cabi.filterinterp_forward_ori(ctx, offs[d][t], filt[d], single) == 0
+            assert torch.equal(pairs[t][d], single), (t, d)
+            assert np.array_equal(cpu(pairs[t][d]), oracle.filterinterp_ori_fwd(cpu(ctx.contiguous()), cpu(offs[d][t]), cpu(filt[d]), fmad=1)), (t, d)
+
+
 @pytest.mark.parametrize("shape", [(1, 32, 36, 62), (2, 19, 18, 31), (1, 8, 72, 124), (1, 3, 5, 7), (1, 196, 9, 13)])
 @pytest.mark.parametrize("align_corners", [True, False])
 def test_pwc_warp_correlation_fused(torch_mod, cabi, oracle, shape, align_corners):

@@ -160,7 +160,8 @@ def filterinterp_forward_ori_multi(input1, flows, input3, outputs):
     if n == 0 or len(outputs) != n:
         return 1
     for fl, out in zip(flows, outputs):
-        if _fi_checks(input1, fl, input3, out) is None or _st_tuple(fl) != _st_tuple(flows[0]) or _st_tuple(out) != _st_tuple(input1):
+        # (layouts compared as _same_strides does: the stride of a size-1 dimension is arbitrary, e.g. after slicing)
+        if _fi_checks(input1, fl, input3, out) is None or not _same_strides(fl, flows[0]) or not _same_strides(out, input1):
             return 1
         _dev(fl), _dev(out)
     b, c, h, w = input1.shape

@@ -1327,6 +1327,9 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
                  : "=&s"(dirty), "=&s"(tflag) : "s"(ws), "s"(ws + g.off_list + tile) : "memory");
     const bool fallback = dirty != 0;
     if (tile == 0 && threadIdx.x == 0) ws[PROJ_WS_FLAG] = 0;               // K0 of the next call starts afresh
+    // (and the tile's word: every word of this buffer is zero between calls, so a call on another frame size, whose records
+    //  lie where this call's list was, finds them empty)
+    if (threadIdx.x == 0 && tflag != 0) ws[g.off_list + tile] = 0;
     if (!fallback && (!fillhole || tflag == 0)) return;
     const int per_img = g.tiles_x * g.tiles_y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1554,17 +1557,18 @@ static bool proj_geometry(int batch, int h, int w, ProjGeom* g, ProjSizes* z) {
 
 struct ProjBuffers { int* words; int* bits; float* planes; };
 static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
-    // the header, the tile records and the scratch planes carry state between calls and start at zero;
-    // the list and the bitmaps are rewritten by every call
-    bool fresh_words = false, fresh_planes = false;
-    size_t plane_bytes = 0;
-    p->words = static_cast<int*>(ws_get(st, WS_PROJ_WORDS, z.words * sizeof(int), true, &fresh_words));
-    p->bits = static_cast<int*>(ws_get(st, WS_PROJ_BITS, z.bit_words * sizeof(int), false, nullptr));
-    p->planes = static_cast<float*>(ws_get(st, WS_PROJ_PLANES, z.plane_floats * sizeof(float), true, &fresh_planes, &plane_bytes));
-    if (!(p->words && p->bits && p->planes)) return false;
-    // the header that says how much of the planes is dirty lives in `words`: a new (zeroed) header beside planes that
-    // were kept would forget it
-    if (fresh_words && !fresh_planes && hipMemsetAsync(p->planes, 0, plane_bytes, st) != hipSuccess) return false;
+    // The header and the tile records (zero between calls) say what the scratch planes hold (zero between calls unless the
+    // header says otherwise), and the bitmaps go with them: the three buffers are one set, allocated and retired together
+    // (workspace.h) -- with separate lifetimes a graph captured before the planes grew would keep the old planes beside a
+    // header that later calls clear after cleaning the NEW planes.
+    const WsSlot slots[3] = {WS_PROJ_WORDS, WS_PROJ_BITS, WS_PROJ_PLANES};
+    const size_t bytes[3] = {z.words * sizeof(int), z.bit_words * sizeof(int), z.plane_floats * sizeof(float)};
+    const bool zero[3] = {true, false, true};
+    void* ptrs[3];
+    if (!ws_get_group(st, slots, bytes, zero, 3, ptrs)) return false;
+    p->words = static_cast<int*>(ptrs[0]);
+    p->bits = static_cast<int*>(ptrs[1]);
+    p->planes = static_cast<float*>(ptrs[2]);
     return true;
 }
 

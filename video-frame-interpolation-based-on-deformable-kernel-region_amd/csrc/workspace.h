@@ -30,4 +30,10 @@ enum WsSlot {
 // *capacity, when asked for, is the size of the returned buffer (at least `bytes`).
 void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, bool* fresh, size_t* capacity = nullptr);
 
+// Buffers that carry state for each other (the projection's header and records say what its scratch planes hold) are
+// (re)allocated TOGETHER: if any of the n slots is too small for its bytes[i], all n get new buffers (zero-filled on
+// `stream` where zero[i]) and the old ones are retired as a set -- a graph captured earlier keeps its own consistent set.
+// false on allocation failure.
+bool ws_get_group(hipStream_t stream, const WsSlot* slots, const size_t* bytes, const bool* zero, int n, void** ptrs);
+
 }  // namespace vfi

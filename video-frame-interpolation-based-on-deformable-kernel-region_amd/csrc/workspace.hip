@@ -1,6 +1,7 @@
 // workspace.hip -- see workspace.h.
 #include "workspace.h"
 
+#include <algorithm>
 #include <deque>
 #include <mutex>
 #include <vector>
@@ -49,6 +50,41 @@ void* ws_get(hipStream_t stream, WsSlot slot, size_t bytes, bool zero_on_alloc, 
     if (fresh) *fresh = true;
     if (capacity) *capacity = want;
     return p;
+}
+
+bool ws_get_group(hipStream_t stream, const WsSlot* slots, const size_t* bytes, const bool* zero, int n, void** ptrs) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    WsEntry* e = nullptr;
+    for (auto& x : g_entries)
+        if (x.device == dev && x.stream == stream) e = &x;
+    if (!e) {
+        g_entries.push_back(WsEntry{dev, stream, {}, {}});
+        e = &g_entries.back();
+    }
+    bool fits = true;
+    for (int i = 0; i < n; ++i) fits = fits && e->ptr[slots[i]] && e->bytes[slots[i]] >= bytes[i];
+    if (!fits) {
+        void* fresh[WS_SLOTS] = {};
+        size_t want[WS_SLOTS] = {};
+        for (int i = 0; i < n; ++i) {
+            want[i] = std::max(bytes[i] + bytes[i] / 4, e->bytes[slots[i]]);        // grow generously, never shrink
+            want[i] = (want[i] + 255) & ~(size_t)255;
+            if (hipMalloc(&fresh[i], want[i]) != hipSuccess || (zero[i] && hipMemsetAsync(fresh[i], 0, want[i], stream) != hipSuccess)) {
+                for (int k = 0; k <= i; ++k)
+                    if (fresh[k]) (void)hipFree(fresh[k]);
+                return false;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            if (e->ptr[slots[i]]) g_retired.emplace_back(dev, e->ptr[slots[i]]);
+            e->ptr[slots[i]] = fresh[i];
+            e->bytes[slots[i]] = want[i];
+        }
+    }
+    for (int i = 0; i < n; ++i) ptrs[i] = e->ptr[slots[i]];
+    return true;
 }
 
 // ---- deterministic image gradients (vfi_common.h)

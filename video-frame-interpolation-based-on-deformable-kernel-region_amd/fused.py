@@ -56,8 +56,9 @@ def FilterInterpolate_ctx_all(ctx0, ctx2, offsets, filter):
     projected flow of direction d at time offset t.  Returns [(ctx0_offset_t, ctx2_offset_t) for t], each pair what
     the reference's call returns -- from one launch per direction that stages every image window once."""
     nt = len(offsets[0])
-    out0 = [torch.empty_like(ctx0) for _ in range(nt)]
-    out2 = [torch.empty_like(ctx2) for _ in range(nt)]
+    # (outputs share the input's layout, strided views included: empty_like would densify a channel slice)
+    out0 = [torch.empty_strided(ctx0.shape, ctx0.stride(), dtype=ctx0.dtype, device=ctx0.device) for _ in range(nt)]
+    out2 = [torch.empty_strided(ctx2.shape, ctx2.stride(), dtype=ctx2.dtype, device=ctx2.device) for _ in range(nt)]
     _check(cabi.filterinterp_forward_ori_multi(ctx0, list(offsets[0]), filter[0], out0), "filterinterp_forward_ori_multi")
     _check(cabi.filterinterp_forward_ori_multi(ctx2, list(offsets[1]), filter[1], out2), "filterinterp_forward_ori_multi")
     return list(zip(out0, out2))
