@@ -7,14 +7,19 @@
 #    flow field and two launches of known traffic (invalid = pure copy-through, zero = zero flow)
 # 3. the FETCH_SIZE calibration probe (tools/probes/fetch_size_calibration.hip): every load flavour on known bytes
 # 4. kernel trace of the projection bench (tools/bench_proj.py): the three launches of a call
+# 5. (round 3) PMC passes over the north-star gate's kernels: the FilterInterpolation C=3 launch and the three launches
+#    of a FlowProjection call -- EA read requests, WRITE_SIZE, instruction and wait counters (tools/prof_fi.py smooth 3,
+#    tools/bench_proj.py)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/probes/fetch_size_calibration.hip -o /tmp/fetchcal || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
+# --no-extras: only the timed region, so that the dominant kernel's row in the stats IS the launch roofline.avg_launch_ms times
+# (the round-2 summary averaged it with the quarter-field launches of the side measurements)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1
 echo bench-trace-done
 for model in smooth quarter zero invalid; do
   for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
@@ -28,4 +33,13 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_FETCH_
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $OUT/cal_RDREQ -- /tmp/fetchcal > /dev/null 2>&1 || exit 1
 echo calibration-done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proj -- python3 $R/tools/bench_proj.py --flows smooth,quarter --iters 50 > $OUT/proj_bench.log 2>&1 || exit 1
+for ctr in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+  n=$(echo $ctr | cut -d' ' -f1)
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/gate_proj_$n -- python3 $R/tools/bench_proj.py --flows smooth --iters 20 > /dev/null 2>&1 || exit 1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/gate_fi3_$n -- python3 $R/tools/prof_fi.py smooth 3 > /dev/null 2>&1 || exit 1
+done
+echo gate-pmc-done
 echo collected > $OUT/done

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(ROOT, "profiles")
 H, W = 1152, 1984
@@ -89,6 +89,38 @@ for model in ("smooth", "quarter"):
                     "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                     "algorithmic_bytes": 1640.0 * PX, "ratio": round((rd + wr) / (1640.0 * PX), 3),
                     "source": "profiles/%s_fi196_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
+
+# 5. the north-star gate's kernels: per-launch PMC means of the FilterInterpolation C=3 launch and of the three launches of a
+#    FlowProjection call (FlowProjection only: the `false` instantiations), and their HBM-side bytes per call
+gate = {"fi_c3": {}, "flowproj": {}}
+for d in sorted(glob.glob(os.path.join(src, "gate_fi3_*"))):
+    for k, v in counters(d, "fi_forward_ori_lds").items():
+        gate["fi_c3"][k] = v
+for d in sorted(glob.glob(os.path.join(src, "gate_proj_*"))):
+    for k, v in counters(d, "proj_").items():
+        if "<true" not in k and "proj_backward" not in k:
+            gate["flowproj"][k] = v
+with open(os.path.join(dst, tag + "_gate_pmc.json"), "w") as fh:
+    json.dump(gate, fh, indent=1, sort_keys=True)
+
+
+def traffic_of(block, name_part):
+    rd = sum(v for k, v in block.items() if k.endswith("TCC_EA0_RDREQ_sum") and name_part in k) * 128.0
+    wr = sum(v for k, v in block.items() if k.endswith("WRITE_SIZE") and name_part in k) * 1024.0
+    return rd, wr
+
+
+if gate["fi_c3"]:
+    rd, wr = traffic_of(gate["fi_c3"], "fi_forward_ori_lds")
+    entries.append({"h": H, "w": W, "flow_model": "smooth", "direct": False, "op": "fi_c3", "kernel": "vfi::fi_forward_ori_lds<false, 0> (C=3)",
+                    "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": 96.0 * PX,
+                    "ratio": round((rd + wr) / (96.0 * PX), 3), "source": "profiles/%s_gate_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
+if gate["flowproj"]:
+    rd, wr = traffic_of(gate["flowproj"], "proj_")
+    entries.append({"h": H, "w": W, "flow_model": "smooth", "direct": False, "op": "flowproj",
+                    "kernel": "vfi::proj_scan4<false> + proj_pull_lean<false> + proj_finish (one FlowProjection call)",
+                    "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": 20.0 * PX,
+                    "ratio": round((rd + wr) / (20.0 * PX), 3), "source": "profiles/%s_gate_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE, summed over the three launches)" % tag})
 with open(os.path.join(dst, "traffic_by_config.json"), "w") as fh:
     json.dump({"entries": entries}, fh, indent=1)
 print(json.dumps(entries, indent=1))

@@ -320,14 +320,142 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
         }
     }
     const float nelems = (float)channel;
+    if (oy < oh && ox + 1 < ow && (ow & 1) == 0) {
+        // the lane's two pixels as one 8-byte store: a wave writes whole 128-byte row segments
+        float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-        if (ox + q < ow && oy < oh) {
-            float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+        for (int ti = 0; ti < D; ++ti) *reinterpret_cast<v2f*>(o + (int64_t)ti * oh * ow) = v2f{acc[0][ti] / nelems, acc[1][ti] / nelems};
+    } else {
 #pragma unroll
-            for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[q][ti] / nelems;
-        }
+        for (int q = 0; q < 2; ++q)
+            if (ox + q < ow && oy < oh) {
+                float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+#pragma unroll
+                for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[q][ti] / nelems;
+            }
+    }
 }
+
+#ifdef VFI_DEV
+// DEVELOPMENT BUILDS ONLY (measured, slower: see the end of this comment).
+// k == 1, strides 1, md == 4 on the matrix cores (round 3; BASELINE.json north_star: "the correlation cost-volume is the
+// one dense-contraction candidate for MFMA").  For one output row y and one displacement row tj the cost volume is the
+// band x2 - x1 in [-4, 4] of the product  C[x1][x2] = sum_c f1[c][y][x1] * f2[c][y + tj - 4][x2]:  a wave owns 16
+// pixels x1 of a row and forms, per displacement row, the two 16x16 tiles that hold its band (x2 in [x0 - 4, x0 + 28))
+// with v_mfma_f32_16x16x4_f32, four channels per instruction -- 18 accumulator tiles (72 registers) per wave, 144 of
+// every 512 products wanted.  The f32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md section 3),
+// so the sums are the sequential-channel-order sums of the other kernels: same bits.  A workgroup of 16 waves owns
+// 64x4 pixels; both maps are staged eight channels at a time as 16-byte units exactly as in corr_forward_k1_rows2.
+// Per four channels a wave reads 1 + 18 operand registers from LDS (ds_read_b32) for 18 MFMAs.
+// Measured on the 1080p pyramid (tools/corr_mfma_ab.py): bit-identical with the vector kernels on every level, and slower --
+// 32 x 288x496: 57.0 us against 38.7 us, 64 x 144x248: 31.1 against 24.0, 96 x 72x124: 39.8 against 19.4 (62 workgroups of 16
+// waves do not fill the chip).  The f32 MFMA runs at the vector units' rate and 72 % of its products fall outside the band.
+template <int MD>
+__global__ __launch_bounds__(1024) void corr_forward_k1_mfma(
+    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
+    int channel, int h, int w, int oh, int ow, int org) {
+    static_assert(MD == 4, "two 16-wide tiles hold a band of 9 around 16 pixels");
+    constexpr int D = 2 * MD + 1;
+    constexpr int TW = 64, TH = 4, LW = TW + 16, LH = TH + 2 * MD;              // window: 80 columns (20 units), 12 rows
+    constexpr int CC = 8, NT = 1024;
+    constexpr int UW = LW / 4, NU = CC * LH * UW, NPT = (NU + NT - 1) / NT;      // 1920 units: 2 per thread
+    constexpr int FU = CC * TH * (TW / 4);                                       // 512 units of the first map
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile[CC][LH][LW];
+    __shared__ __attribute__((aligned(16))) float f1s[CC][TH][TW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = wave & 3, ry = wave >> 2;                                    // 16-pixel segment and row of the tile
+    const int b = blockIdx.z;
+    const int64_t plane = (int64_t)h * w;
+    const float* f1 = in1 + (int64_t)b * channel * plane;
+    const float* f2 = in2 + (int64_t)b * channel * plane;
+    const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;   // window origin (a multiple of 4 columns)
+
+    int soff[NPT], sch[NPT];
+    bool sok[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (LH * UW), rem = e - c * (LH * UW);
+        const int r = rem / UW, col = 4 * (rem - r * UW);
+        const int gy = wy0 + r, gx = wx0 + col;
+        sch[k] = c;
+        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = sok[k] ? gy * w + gx : 0;
+    }
+    int foff, fch;
+    bool fok;
+    {
+        const int e = tid;
+        const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
+        const int gy = blockIdx.y * TH + rem / (TW / 4) + org, gx = blockIdx.x * TW + 4 * (rem % (TW / 4)) + org;
+        fch = c;
+        fok = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff = fok ? gy * w + gx : 0;
+    }
+
+    v4f acc[D][2];
+#pragma unroll
+    for (int tj = 0; tj < D; ++tj) { acc[tj][0] = v4f{0.0f, 0.0f, 0.0f, 0.0f}; acc[tj][1] = v4f{0.0f, 0.0f, 0.0f, 0.0f}; }
+
+    v4f nv[NPT], nf;
+    const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch = [&](int c0) {
+        const int cn = min(CC, channel - c0);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const v4f*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+        nf = (fok && fch < cn) ? *reinterpret_cast<const v4f*>(f1 + (int64_t)(c0 + fch) * plane + foff) : zero;
+    };
+    fetch(0);
+    const int kk = lane >> 4, jj = lane & 15;                                    // operand element: channel kk of the step, column jj
+    for (int c0 = 0; c0 < channel; c0 += CC) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < NU) reinterpret_cast<v4f*>(&tile[0][0][0])[e] = nv[k];
+        }
+        if (tid < FU) reinterpret_cast<v4f*>(&f1s[0][0][0])[tid] = nf;
+        __syncthreads();
+        if (c0 + CC < channel) fetch(c0 + CC);
+        // (channels past the end were staged as zeros: they add exact zeros)
+#pragma unroll
+        for (int ks = 0; ks < CC / 4; ++ks) {
+            const float a = f1s[4 * ks + kk][ry][16 * seg + jj];
+#pragma unroll
+            for (int tj = 0; tj < D; ++tj) {
+                const float b0 = tile[4 * ks + kk][ry + tj][16 * seg + jj];
+                const float b1 = tile[4 * ks + kk][ry + tj][16 * seg + 16 + jj];
+                acc[tj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[tj][0], 0, 0, 0);
+                acc[tj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[tj][1], 0, 0, 0);
+            }
+        }
+    }
+    // the band: out[tj][ti][x1] = C_tj[x1][x1 + ti] (column 0 of tile 0 is x2 = x0 - 4).  Lane l, register r of a tile hold
+    // row 4 (l >> 4) + r, column l & 15: through an LDS image of the wave's two tiles, [16 rows][32 + 1 columns]
+    __syncthreads();
+    float* img = &tile[0][0][0] + wave * (16 * 33);                              // 16 waves x 528 floats < the window array
+    const float nelems = (float)channel;
+    const int oy = blockIdx.y * TH + ry, ox0 = blockIdx.x * TW + 16 * seg;
+#pragma unroll
+    for (int tj = 0; tj < D; ++tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            img[(4 * (lane >> 4) + r) * 33 + (lane & 15)] = acc[tj][0][r];
+            img[(4 * (lane >> 4) + r) * 33 + 16 + (lane & 15)] = acc[tj][1][r];
+        }
+        // (a wave's own LDS writes are visible to its reads in order: no barrier)
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            const int ti = 4 * pass + (lane >> 4), i = lane & 15;
+            if (ti < D && oy < oh && ox0 + i < ow)
+                out[((int64_t)b * (D * D) + tj * D + ti) * oh * ow + (int64_t)oy * ow + ox0 + i] = img[i * 33 + i + ti] / nelems;
+        }
+    }
+}
+#endif  // VFI_DEV
 
 // k == 1, strides 1, tiny frames (the coarsest pyramid levels: a few hundred pixels, up to 196
 // channels): one thread per output element, x fastest, so a wave reads 64 consecutive pixels of each
@@ -617,9 +745,13 @@ VFI_KNOB(long long, g_corr_big_threshold, 256);
 VFI_KNOB(long long, g_corr_flat_threshold, 64);     // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
 VFI_KNOB(int, g_corr_rows2, 1);                     // two pixels per lane in the tiled kernel
 #ifdef VFI_DEV
+static int g_corr_mfma = 0;                         // the matrix-core kernel for the aligned levels (corr_forward_k1_mfma)
+#endif
+#ifdef VFI_DEV
 extern "C" void vfi_dev_correlation(long long big_threshold, long long flat_threshold, int rows2) {
     g_corr_big_threshold = big_threshold; g_corr_flat_threshold = flat_threshold; g_corr_rows2 = rows2;
 }
+extern "C" void vfi_dev_correlation_mfma(int on) { g_corr_mfma = on; }
 #endif
 
 extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kernel_size, int max_displacement,
@@ -655,6 +787,12 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
             const int64_t total = (int64_t)batch * oc * oh * ow;
             hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,
                                input2, output, batch, channel, h, w, oh, ow, max_displacement - pad_size);
+#ifdef VFI_DEV
+        } else if (g_corr_mfma && aligned) {
+            const dim3 grid((ow + 63) / 64, (oh + 3) / 4, batch);
+            hipLaunchKernelGGL(corr_forward_k1_mfma<4>, grid, dim3(1024, 1, 1), 0, st, input1, input2, output,
+                               channel, h, w, oh, ow, max_displacement - pad_size);
+#endif
         } else if (g_corr_rows2 && aligned) {
             const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
             hipLaunchKernelGGL(corr_forward_k1_rows2<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,

@@ -67,6 +67,9 @@ namespace vfi {
 #define PROJ_ADD_CELL 32            // addends per cell that fit beside it in 32 bits
 #define PROJ_CLS_BITS 6             // binary orders of magnitude of weight per accumulation pass (DepthFlowProjection)
 #define PROJ_BLOCK_CAP 64           // output tiles one block may reach before the call takes the fallback
+#define PROJ_STAB 16                // K0's table of merged record updates: 16 x 16 tiles around the workgroup's four,
+#define PROJ_STAB_X0 6              // from 6 tile columns (384 pixels) left of them
+#define PROJ_STAB_Y0 8              // and 8 tile rows (128 pixels) above
 
 // workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
 // read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by K1, read by K2 and by
@@ -357,8 +360,11 @@ template <bool DEPTH>
 __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int groups_x, int* __restrict__ ws,
                                                   float* __restrict__ planes, int64_t plane_floats) {
     __shared__ int sblk[16][7];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits
+    __shared__ __attribute__((aligned(16))) int stab[PROJ_STAB * PROJ_STAB][8];   // the workgroup's merged updates: [tile slot][record field]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 112) sblk[tid / 7][tid % 7] = (tid % 7 == 0 || tid % 7 == 2) ? INT_MAX : (tid % 7 == 1 || tid % 7 == 3) ? INT_MIN : 0;
+    reinterpret_cast<uint4*>(&stab[tid][0])[0] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(&stab[tid][0])[1] = make_uint4(0u, 0u, 0u, 0u);
     const int per_img = groups_x * g.tiles_y;
     const int item = band_item(blockIdx.x, gridDim.x);
     const int b = item / per_img;
@@ -405,6 +411,9 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
                 }
             }
         }
+#if PROJ_DEV_SKIP == 6      // (development: K0 = its loads and per-pixel arithmetic only)
+    if (dlmin != 12345) { if (vbits == 0x7fffffff) ws[4] = dlmax + dtmin + dtmax + cbits + mbits; return; }
+#endif
     // a block is four lanes wide
     dlmin = quad_min(dlmin); dlmax = quad_max(dlmax); dtmin = quad_min(dtmin); dtmax = quad_max(dtmax);
     vbits = quad_max(vbits); cbits = quad_max(cbits); mbits = quad_max(mbits);
@@ -414,11 +423,67 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         atomicMax(&e[4], vbits); atomicMax(&e[5], cbits); atomicMax(&e[6], mbits);
     }
     __syncthreads();
-    // wave w: the four blocks of tile column w, spoken for by lanes 15, 31, 47, 63 as in proj_scan
-    const int* e = sblk[4 * wave + (lane >> 4)];
-    const int xb = (gxi * 4 + wave) * PROJ_TW + (lane >> 4) * PROJ_BLK + 15;      // the block's last column
-    const bool speaker = (lane & 15) == 15 && xb - 15 < g.w;
-    scan_scatter(g, ws, b, lane, xb, y0, speaker ? e[0] : INT_MAX, e[1], e[2], e[3], e[4], e[5], e[6]);
+    // The tail (round 3).  Thread (block k, slot j): block k of the workgroup's 16 and the j-th of the <= 2 x 8 output tiles it
+    // can reach; the part of the block that can reach that tile goes, field by field, into a table of the workgroup's
+    // merged updates in LDS (cheap integer atomics); after a barrier the table's non-empty (tile, field) pairs go to the
+    // records with ONE atomic instruction per eight tiles -- ~6 vector-memory atomic instructions per workgroup where
+    // the per-wave readlane loops of scan_scatter issued ~24 (and ~700 scalar instructions per wave: 5 of this
+    // kernel's 11 us at 1080p).
+    {
+        const int k = tid >> 4, j = tid & 15;
+        const int* e = sblk[k];
+        const int bx0 = gxi * 4 * PROJ_TW + k * PROJ_BLK, bx1 = min(bx0 + PROJ_BLK - 1, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
+        const int dlmin_ = e[0], dlmax_ = e[1], dtmin_ = e[2], dtmax_ = e[3];
+        const bool any = dlmin_ != INT_MAX && bx0 < g.w;
+#if PROJ_DEV_SKIP == 5      // (development: K0 without its scatter)
+        if (dlmin_ != 12345) return;
+#endif
+        // top-left targets of the block lie in [X0, X1] x [Y0, Y1]; a target (L, T) feeds columns L, L + 1, rows T, T + 1
+        const int X0 = max(bx0 + dlmin_, 0), X1 = min(bx1 + dlmax_, g.w - 1);
+        const int Y0 = max(y0 + dtmin_, 0), Y1 = min(by1 + dtmax_, g.h - 1);
+        const int a0 = X0 / PROJ_TW, a1 = min(X1 + 1, g.w - 1) / PROJ_TW, c0 = Y0 / PROJ_TH, c1 = min(Y1 + 1, g.h - 1) / PROJ_TH;
+        const int nx = a1 - a0 + 1, ny = c1 - c0 + 1;
+        const bool wild = any && nx * ny > PROJ_BLOCK_CAP;
+        if (wild && j == 0) ws[PROJ_WS_FLAG] = 1;               // the call takes the fallback; records no longer matter
+        const bool wide = any && !wild && (nx > 2 || ny > 8);   // more tiles than slots: thread j == 0 walks them all
+        const int torg_x = gxi * 4 - PROJ_STAB_X0, torg_y = tyi - PROJ_STAB_Y0;
+        auto update = [&](int tx, int ty) {
+            const int ox0 = tx * PROJ_TW, oy0 = ty * PROJ_TH;
+            const int tx1 = min(ox0 + PROJ_TW - 1, g.w - 1), ty1 = min(oy0 + PROJ_TH - 1, g.h - 1);
+            // a pixel at x has L in [x + dlmin, x + dlmax]; the tile takes L in [ox0 - 1, tx1]
+            const int sx0 = max(bx0, ox0 - 1 - dlmax_), sx1 = min(bx1, tx1 - dlmin_);
+            const int sy0 = max(y0, oy0 - 1 - dtmax_), sy1 = min(by1, ty1 - dtmin_);
+            if (sx0 > sx1 || sy0 > sy1) return;
+            const int f[7] = {32767 - sx0, 32767 - sy0, sx1 + 1, sy1 + 1, e[4], e[5], e[6]};
+            const int rx = tx - torg_x, ry = ty - torg_y;
+            if ((unsigned)rx < PROJ_STAB && (unsigned)ry < PROJ_STAB) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) atomicMax(&stab[ry * PROJ_STAB + rx][q], f[q]);
+            } else {                                            // beyond the table (flows of hundreds of pixels): straight to the record
+                int* rec = ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) atomicMax(&rec[q], f[q]);
+            }
+        };
+        if (any && !wild && !wide) {
+            const int tx = a0 + (j & 1), ty = c0 + (j >> 1);
+            if (tx <= a1 && ty <= c1) update(tx, ty);
+        } else if (wide && j == 0) {
+            for (int ty = c0; ty <= c1; ++ty)
+                for (int tx = a0; tx <= a1; ++tx) update(tx, ty);
+        }
+        __syncthreads();
+        // lane = (tile slot, field): eight slots per wave instruction
+#pragma unroll
+        for (int pass = 0; pass < PROJ_STAB * PROJ_STAB / 32; ++pass) {
+            const int sl = 32 * pass + (tid >> 3), q = tid & 7;
+            const int v = stab[sl][q];
+            if (v != 0 && q < 7) {
+                const int tx = torg_x + (sl % PROJ_STAB), ty = torg_y + (sl / PROJ_STAB);
+                atomicMax(ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS + q, v);
+            }
+        }
+    }
 }
 
 // the two halves of a packed sum, exactly: S = hi * 2^32 + lo with both in int32
