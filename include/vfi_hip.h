@@ -262,10 +262,11 @@ int vfi_flow_upsample4(const float* input, float* output,
                        vfi_strides sq, vfi_strides so,
                        vfi_stream_t stream);
 
-/* the same upsample fused into (Depth)FlowProjection: the splat reads the quarter-resolution flow
- * [B,2,hq,wq] and forms each source pixel's flow on the fly; count [B,1,4hq,4wq] and output
- * [B,2,4hq,4wq] as vfi_flowprojection_forward.  Results equal vfi_flow_upsample4 followed by the
- * unfused projection bit for bit. */
+/* forward_flownets + FlowProject in one call: the quarter-resolution flow [B,2,hq,wq] is upsampled
+ * into a per-stream scratch tensor of the library and projected; count [B,1,4hq,4wq] and output
+ * [B,2,4hq,4wq] as vfi_flowprojection_forward.  Results equal vfi_flow_upsample4 followed by
+ * vfi_[depth]flowprojection_forward bit for bit (it is those two steps without a caller-side
+ * tensor). */
 int vfi_flowprojection_forward_up4(const float* flow_q, float* count, float* output,
                                    int batch, int hq, int wq, float mul0, float mul1, int fillhole,
                                    vfi_strides sq, vfi_strides sc, vfi_strides so,

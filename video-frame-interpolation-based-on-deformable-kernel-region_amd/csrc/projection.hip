@@ -14,15 +14,17 @@
 //
 // How (owner computes, pull; no global atomics on the normal path).  The frame is cut into 64x16
 // OUTPUT tiles and, as a source, into 16x16 BLOCKS.
-//   K0  proj_scan    reads the flow once: per block the range of its integer displacements and its largest
+//   K0  proj_scan4   reads the flow once: per block the range of its integer displacements and its largest
 //                    addends; for every output tile the block can reach, the part of the block that can reach
-//                    it is merged into that tile's SOURCE RECTANGLE (a few atomicMax on a 32-byte record).
-//   K1  proj_pull    one workgroup per output tile: walks its source rectangle (for a smooth field: the tile
-//                    shifted by the flow and a few pixels larger, ~1.3 source pixels per output pixel),
+//                    it is merged into that tile's SOURCE RECTANGLE (a 32-byte record, fields merged by max:
+//                    first in a table of the workgroup in LDS, then by a few atomicMax instructions).
+//   K1  proj_pull_lean  one workgroup per output tile: walks its source rectangle (for a smooth field: the tile
+//                    shifted by the flow and a few pixels larger, ~1.4 source pixels per output pixel),
 //                    accumulates in LDS and writes count and the normalised flow once, coalesced, plus two
 //                    bitmaps of "count != 0" and whether the tile has holes.
 //   K2  proj_finish  hole filling for the tiles that have holes (bitmap searches in registers instead of the
 //                    reference's cell-by-cell walks); resets the per-call state.
+// (proj_scan / proj_pull: the same two steps with 4-byte lanes, for flows whose rows are not 16-byte aligned.)
 // K1 writes every cell of count and output, so callers need not zero-fill them (the reference's
 // callers must: its splat accumulates into them).  Nothing of a call's state crosses to the host and
 // no kernel argument changes from call to call: a captured graph is replayable.
@@ -97,19 +99,15 @@ struct ProjGeom {
     int h, w, tiles_x, tiles_y, ntiles, rmw, cmw, rowmap, colmap, off_tile, off_list;
 };
 
-// Where the flow of a source pixel comes from.  UP == false: the full-resolution flow tensor of the
-// reference's FlowProjection.  UP == true: the network's quarter-resolution flow; the pixel's flow is
-// nn.Upsample(scale_factor=4, mode='bilinear') of (m0 * flow) * m1, formed on the fly -- the x4
-// upsampled tensor of forward_flownets (networks/DAIN_slowmotion.py:204-216) is never materialised.
+// The flow (and depth) planes a projection reads: the full-resolution flow tensor of the reference's FlowProjection.
+// (The network's quarter-resolution flow goes through flow_upsample4 first: vfi_*_forward_up4 below.)
 // Row strides are 32-bit here (the host checks that every in-plane offset fits): the kernels address a
 // plane as uniform base + 32-bit offset.
 struct ProjSrc {
-    const float* flow;      // [B,2,h,w], or UP: [B,2,hq,wq]
+    const float* flow;      // [B,2,h,w]
     const float* depth;     // [B,1,h,w] (DEPTH only)
     int64_t fb, fc, db;     // flow batch / channel stride, depth batch stride
     int fh, dh;             // row strides
-    int hq, wq;             // quarter-resolution size (UP only)
-    float m0, m1;           // div_flow, time offset (UP only)
 };
 
 // torch's upsample_bilinear2d, align_corners=False, scale factor 4 (ATen UpSampleBilinear2d):
@@ -139,22 +137,20 @@ __device__ __forceinline__ float up4_sample(const float* __restrict__ plane, int
                      plane[(int64_t)ty.i1 * hs + tx.i0], plane[(int64_t)ty.i1 * hs + tx.i1], ty, tx, m0, m1);
 }
 
-// A source pixel in two steps, so that a caller can have the loads of many pixels in flight before it
-// works on the first: pix_load only issues loads (raw values, no arithmetic on them), pix_flow turns
-// them into the pixel's flow.
+// A source pixel's raw values: pix_load only issues loads, so that a caller can have the loads of many pixels in flight
+// before it works on the first.
 // Addressing is buffer-style: a wave-uniform descriptor per plane + a 32-bit byte offset split into a
 // per-lane part and a wave-uniform part (the row a wave works on advances on the scalar unit, at no
 // vector instruction per pixel); offsets past the plane read as 0.
-template <bool UP> struct ProjPix { float v[UP ? 8 : 2]; float d; };
+struct ProjPix { float fx, fy, d; };
 struct ProjPlanes { __amdgpu_buffer_rsrc_t f0, f1, d; };
 
-template <bool DEPTH, bool UP>
+template <bool DEPTH>
 __device__ __forceinline__ ProjPlanes proj_planes(const ProjSrc& s, int b, int h, int w) {
-    const int rows = UP ? s.hq : h, cols = UP ? s.wq : w;
     const float* f0 = s.flow + (int64_t)b * s.fb;
     ProjPlanes p;
-    p.f0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ((rows - 1) * s.fh + cols) * 4, 0x00020000);
-    p.f1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + s.fc), 0, ((rows - 1) * s.fh + cols) * 4, 0x00020000);
+    p.f0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ((h - 1) * s.fh + w) * 4, 0x00020000);
+    p.f1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + s.fc), 0, ((h - 1) * s.fh + w) * 4, 0x00020000);
     p.d = p.f0;
     if constexpr (DEPTH)
         p.d = __builtin_amdgcn_make_buffer_rsrc((void*)(s.depth + (int64_t)b * s.db), 0, ((h - 1) * s.dh + w) * 4, 0x00020000);
@@ -165,35 +161,15 @@ __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int voff, int
 }
 
 // pixel (x, yl + yu): x and yl may differ from lane to lane, yu is wave-uniform.  Inside the frame.
-template <bool DEPTH, bool UP>
-__device__ __forceinline__ ProjPix<UP> pix_load(const ProjSrc& s, const ProjPlanes& p, int x, int yl, int yu) {
-    ProjPix<UP> r;
-    if constexpr (UP) {
-        const UpTap ty = up4_tap(yl + yu, s.hq), tx = up4_tap(x, s.wq);
-        const int r0 = ty.i0 * s.fh, r1 = ty.i1 * s.fh;
-        r.v[0] = buf_f32(p.f0, (r0 + tx.i0) * 4, 0); r.v[1] = buf_f32(p.f0, (r0 + tx.i1) * 4, 0);
-        r.v[2] = buf_f32(p.f0, (r1 + tx.i0) * 4, 0); r.v[3] = buf_f32(p.f0, (r1 + tx.i1) * 4, 0);
-        r.v[4] = buf_f32(p.f1, (r0 + tx.i0) * 4, 0); r.v[5] = buf_f32(p.f1, (r0 + tx.i1) * 4, 0);
-        r.v[6] = buf_f32(p.f1, (r1 + tx.i0) * 4, 0); r.v[7] = buf_f32(p.f1, (r1 + tx.i1) * 4, 0);
-    } else {
-        const int vo = (yl * s.fh + x) * 4, so = yu * s.fh * 4;
-        r.v[0] = buf_f32(p.f0, vo, so);
-        r.v[1] = buf_f32(p.f1, vo, so);
-    }
+template <bool DEPTH>
+__device__ __forceinline__ ProjPix pix_load(const ProjSrc& s, const ProjPlanes& p, int x, int yl, int yu) {
+    ProjPix r;
+    const int vo = (yl * s.fh + x) * 4, so = yu * s.fh * 4;
+    r.fx = buf_f32(p.f0, vo, so);
+    r.fy = buf_f32(p.f1, vo, so);
     r.d = 1.0f;
     if constexpr (DEPTH) r.d = buf_f32(p.d, (yl * s.dh + x) * 4, yu * s.dh * 4);
     return r;
-}
-template <bool UP>
-__device__ __forceinline__ void pix_flow(const ProjSrc& s, const ProjPix<UP>& r, int x, int y, float& fx, float& fy) {
-    if constexpr (UP) {
-        const UpTap ty = up4_tap(y, s.hq), tx = up4_tap(x, s.wq);
-        fx = up4_blend(r.v[0], r.v[1], r.v[2], r.v[3], ty, tx, s.m0, s.m1);
-        fy = up4_blend(r.v[4], r.v[5], r.v[6], r.v[7], ty, tx, s.m0, s.m1);
-    } else {
-        fx = r.v[0];
-        fy = r.v[1];
-    }
 }
 // The reference's test 0 <= x2 <= w - 1 (flowprojection_cuda_kernel.cu:69) as ONE unsigned comparison of
 // the float's bits with those of (float)(w - 1): non-negative floats order like their bit patterns, negative
@@ -289,7 +265,7 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
 // once).  Per 16x16 block: the range of (L - x) and of (T - y) over its valid pixels; from it the output tiles the
 // block can reach, and for each of them the part of the block that can -- merged into that tile's source
 // rectangle with atomicMax (fields stored so that 0 means "nothing").
-template <bool DEPTH, bool UP>
+template <bool DEPTH>
 __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __restrict__ ws, float* __restrict__ planes,
                                                 int64_t plane_floats) {
     const int64_t dirty = proj_dirty_floats(ws);
@@ -307,20 +283,19 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
     const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
     const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH;
     const int xc = min(x, g.w - 1);
-    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
+    const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
     int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
-    constexpr int GROUP = UP ? 4 : PROJ_TH;                 // rows whose loads are issued together
+    constexpr int GROUP = PROJ_TH;                          // rows whose loads are issued together
 #pragma unroll 1
     for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
-        ProjPix<UP> raw[GROUP];
+        ProjPix raw[GROUP];
 #pragma unroll
-        for (int k = 0; k < GROUP; ++k) raw[k] = pix_load<DEPTH, UP>(src, pl, xc, 0, min(y0 + r0 + k, g.h - 1));
+        for (int k = 0; k < GROUP; ++k) raw[k] = pix_load<DEPTH>(src, pl, xc, 0, min(y0 + r0 + k, g.h - 1));
 #pragma unroll
         for (int k = 0; k < GROUP; ++k) {
             const int y = y0 + r0 + k;
-            float fx, fy;
-            pix_flow<UP>(src, raw[k], xc, min(y, g.h - 1), fx, fy);
+            const float fx = raw[k].fx, fy = raw[k].fy;
             int L, T;
             const bool valid = pix_target(fx, fy, x, y, wbits, hbits, L, T) && x < g.w && y < g.h;
             const int dl = L - x, dt = T - y;
@@ -371,7 +346,7 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
     const int rem = item - b * per_img;
     const int tyi = rem / groups_x, gxi = rem - tyi * groups_x;
     const int x0 = gxi * 4 * PROJ_TW + 4 * lane, y0 = tyi * PROJ_TH, yw = y0 + 4 * wave;
-    const ProjPlanes pl = proj_planes<DEPTH, false>(src, b, g.h, g.w);
+    const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
     proj_v4f qx[4], qy[4], qd[4];
 #pragma unroll
@@ -537,7 +512,7 @@ template <bool DEPTH> struct ProjLds {
 
 // The fallback of K1 (a block of K0 reached too many tiles): the reference's own scheme -- this tile as SOURCE tile,
 // global atomics into the dense scratch planes [value x | value y | count][batch][h][w] of the workspace (zero between calls)
-template <bool DEPTH, bool UP, int NW>
+template <bool DEPTH, int NW>
 __device__ __forceinline__ void pull_fallback(const ProjSrc& src, const ProjPlanes& pl, const ProjGeom& g, float* __restrict__ planes,
                                               int b, int ox0, int oy0, int lane, int wave) {
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
@@ -550,9 +525,8 @@ __device__ __forceinline__ void pull_fallback(const ProjSrc& src, const ProjPlan
     for (int r = 0; r < PROJ_TH / NW; ++r) {
         const int y = oy0 + wave * (PROJ_TH / NW) + r;
         if (x >= g.w || y >= g.h) continue;
-        float fx, fy;
-        const ProjPix<UP> p = pix_load<DEPTH, UP>(src, pl, x, 0, y);
-        pix_flow<UP>(src, p, x, y, fx, fy);
+        const ProjPix p = pix_load<DEPTH>(src, pl, x, 0, y);
+        const float fx = p.fx, fy = p.fy;
         int L, T;
         if (!pix_target(fx, fy, x, y, wbits, hbits, L, T)) continue;
         const int R = min(L + 1, g.w - 1), Bm = min(T + 1, g.h - 1);
@@ -620,7 +594,7 @@ __device__ __forceinline__ void pull_add(unsigned long long* accv, typename Proj
 }
 
 // VEC: the flow (and depth) rows are 16-byte aligned, so a lane can load four pixels at once
-template <bool DEPTH, bool UP, bool VEC>
+template <bool DEPTH, bool VEC>
 __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
     int64_t cb, int ch, int vec_ok, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats) {
@@ -649,13 +623,13 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     }
     int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
     const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5], e6 = entry[6];
-    const ProjPlanes pl = proj_planes<DEPTH, UP>(src, b, g.h, g.w);
+    const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
 
     if (fallback) {
         __syncthreads();
         if (tid < 7) entry[tid] = 0;
-        pull_fallback<DEPTH, UP, PROJ_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
+        pull_fallback<DEPTH, PROJ_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
         return;
     }
 
@@ -736,21 +710,17 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
                 const bool lane_on = lr < rpi;
                 const int step = PROJ_NW * rpi;
                 for (int row0 = wave * rpi; row0 < uh; row0 += CH * step) {
-                    ProjPix<UP> raw[CH];
+                    ProjPix raw[CH];
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
-#pragma unroll
-                        for (int j = 0; j < (UP ? 8 : 2); ++j) raw[k].v[j] = 0.0f;
-                        raw[k].d = 0.0f;
-                        if (row0 + k * step < uh) raw[k] = pix_load<DEPTH, UP>(src, pl, px, lr, uy0 + row0 + k * step);    // (past the plane: reads 0)
+                        raw[k].fx = raw[k].fy = raw[k].d = 0.0f;
+                        if (row0 + k * step < uh) raw[k] = pix_load<DEPTH>(src, pl, px, lr, uy0 + row0 + k * step);    // (past the plane: reads 0)
                     }
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         const int rowk = row0 + k * step + lr;
                         const int py = uy0 + rowk;
-                        float fx, fy;
-                        pix_flow<UP>(src, raw[k], px, py, fx, fy);
-                        pull_add<DEPTH>(accv, accc, fx, fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn,
+                        pull_add<DEPTH>(accv, accc, raw[k].fx, raw[k].fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn,
                                         cls, ncls, emax);
                     }
                 }
@@ -1041,11 +1011,11 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
         ws[PROJ_WS_DIRTY] = fallback ? (int)(unsigned)(plane_floats & 0xffffffffll) : 0;
         ws[PROJ_WS_DIRTY + 1] = fallback ? (int)(plane_floats >> 32) : 0;
     }
-    const ProjPlanes pl = proj_planes<DEPTH, false>(src, b, g.h, g.w);
+    const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     __syncthreads();
     if (tid < 7) entry[tid] = 0;                            // the record is in registers: empty for the next call
     if (fallback) {
-        pull_fallback<DEPTH, false, PL_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
+        pull_fallback<DEPTH, PL_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
         return;
     }
 
@@ -1640,15 +1610,14 @@ static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
 // every in-plane element offset of a [*, *, h, w] tensor with row stride sh fits 31 bits
 static bool fits32(int64_t sh, int h, int w) { return sh >= 0 && sh * (int64_t)(h - 1) + w < ((int64_t)1 << 31); }
 
-// s1 = strides of `out` (the reference binding shares them with the input flow)
-template <bool DEPTH, bool UP>
-static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, float m0, float m1, const float* in2,
-                           float* count, float* out, int batch, int h, int w, int fillhole, vfi_strides s1,
-                           vfi_strides s2, vfi_strides sc, hipStream_t st) {
+// sf = strides of the flow, s1 = strides of `out` (the reference binding shares them)
+template <bool DEPTH>
+static int project_forward(const float* flow, vfi_strides sf, const float* in2, float* count, float* out, int batch, int h, int w,
+                           int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
     ProjGeom g;
     ProjSizes z;
     if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
-    if (!fits32(sf.h, UP ? hq : h, UP ? wq : w) || !fits32(s1.h, h, w) || !fits32(sc.h, h, w) || (DEPTH && !fits32(s2.h, h, w)))
+    if (!fits32(sf.h, h, w) || !fits32(s1.h, h, w) || !fits32(sc.h, h, w) || (DEPTH && !fits32(s2.h, h, w)))
         return VFI_ERR_SHAPE;
     ProjBuffers p;
     if (!proj_buffers(st, z, &p)) return VFI_ERR_LAUNCH;
@@ -1656,16 +1625,15 @@ static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, fl
     src.flow = flow; src.depth = in2;
     src.fb = sf.b; src.fc = sf.c; src.db = DEPTH ? s2.b : 0;
     src.fh = (int)sf.h; src.dh = DEPTH ? (int)s2.h : 0;
-    src.hq = hq; src.wq = wq; src.m0 = m0; src.m1 = m1;
     // 16-byte lanes need 16-byte aligned rows
-    const bool vec_in = !UP && (uintptr_t)flow % 16 == 0 && sf.b % 4 == 0 && sf.c % 4 == 0 && sf.h % 4 == 0 &&
+    const bool vec_in = (uintptr_t)flow % 16 == 0 && sf.b % 4 == 0 && sf.c % 4 == 0 && sf.h % 4 == 0 &&
                         (!DEPTH || ((uintptr_t)in2 % 16 == 0 && s2.b % 4 == 0 && s2.h % 4 == 0));
     if (vec_in) {
         const int groups_x = (g.tiles_x + 3) / 4;
         hipLaunchKernelGGL((proj_scan4<DEPTH>), dim3(batch * g.tiles_y * groups_x), dim3(256), 0, st, src, g, groups_x,
                            p.words, p.planes, (int64_t)z.plane_floats);
     } else {
-        hipLaunchKernelGGL((proj_scan<DEPTH, UP>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
+        hipLaunchKernelGGL((proj_scan<DEPTH>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
                            (int64_t)z.plane_floats);
     }
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
@@ -1679,10 +1647,10 @@ static int project_forward(const float* flow, vfi_strides sf, int hq, int wq, fl
     else
 #endif
     if (vec_in)
-        hipLaunchKernelGGL((proj_pull<DEPTH, false, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+        hipLaunchKernelGGL((proj_pull<DEPTH, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     else
-        hipLaunchKernelGGL((proj_pull<DEPTH, UP, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+        hipLaunchKernelGGL((proj_pull<DEPTH, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
@@ -1728,25 +1696,25 @@ extern "C" int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stre
     ProjSizes z;
     if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
     ProjBuffers p;
-    return proj_buffers((hipStream_t)stream, z, &p) ? VFI_OK : VFI_ERR_LAUNCH;
+    if (!proj_buffers((hipStream_t)stream, z, &p)) return VFI_ERR_LAUNCH;
+    // (and the scratch tensor of the *_forward_up4 entry points, should the caller capture one of those)
+    return ws_get((hipStream_t)stream, WS_PROJ_UPFLOW, (size_t)batch * 2 * h * w * sizeof(float), false, nullptr) ? VFI_OK : VFI_ERR_LAUNCH;
 }
 
 extern "C" int vfi_flowprojection_forward(const float* input1, float* count, float* output, int batch, int h, int w,
                                            int fillhole, vfi_strides s1, vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !count || !output) return VFI_ERR_SHAPE;
-    return project_forward<false, false>(input1, s1, 0, 0, 1.0f, 1.0f, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc,
-                                         (hipStream_t)stream);
+    return project_forward<false>(input1, s1, nullptr, count, output, batch, h, w, fillhole, s1, s1, sc, (hipStream_t)stream);
 }
 
 extern "C" int vfi_depthflowprojection_forward(const float* input1, const float* input2, float* count, float* output,
                                                 int batch, int h, int w, int fillhole, vfi_strides s1, vfi_strides s2,
                                                 vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !count || !output) return VFI_ERR_SHAPE;
-    return project_forward<true, false>(input1, s1, 0, 0, 1.0f, 1.0f, input2, count, output, batch, h, w, fillhole, s1, s2, sc,
-                                        (hipStream_t)stream);
+    return project_forward<true>(input1, s1, input2, count, output, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
 }
 
-// ---- fused glue: the network's quarter-resolution flow goes straight into the splat
+// ---- fused glue: forward_flownets + FlowProject (networks/DAIN_slowmotion.py:204-216, 301-308)
 extern "C" int vfi_flow_upsample4(const float* input, float* output, int batch, int channels, int hq, int wq,
                                    float mul0, float mul1, vfi_strides sq, vfi_strides so, vfi_stream_t stream) {
     if (batch <= 0 || channels <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !input || !output)
@@ -1756,13 +1724,32 @@ extern "C" int vfi_flow_upsample4(const float* input, float* output, int batch, 
     return launch_status();
 }
 
+// The quarter-resolution flow of the network -> its projection, in one call: x4 upsample of (mul0 * flow) * mul1 into a
+// per-stream scratch tensor, then the projection above.  (Rounds 1-2 formed the upsample inside the projection kernels'
+// source reads -- the full-resolution flow never existed -- at 4-byte lanes and eight taps per source pixel: 108 us at 1080p.
+// With round 3's kernels the two steps take 10 + 31 us and the 18 MB round trip through the caches costs less than
+// the fusion saved; same arithmetic, so the same bits as vfi_flow_upsample4 followed by vfi_[depth]flowprojection_forward.)
+template <bool DEPTH>
+static int project_forward_up4(const float* flow_q, vfi_strides sq, int hq, int wq, float m0, float m1, const float* in2,
+                               float* count, float* out, int batch, int fillhole, vfi_strides so, vfi_strides s2, vfi_strides sc,
+                               hipStream_t st) {
+    const int h = 4 * hq, w = 4 * wq;
+    const int64_t plane = (int64_t)h * w;
+    float* full = static_cast<float*>(ws_get(st, WS_PROJ_UPFLOW, (size_t)batch * 2 * plane * sizeof(float), false, nullptr));
+    if (!full) return VFI_ERR_LAUNCH;
+    const vfi_strides sfull{2 * plane, plane, (int64_t)w};
+    hipLaunchKernelGGL(flow_upsample4, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, st, flow_q, full, 2, hq, wq, m0, m1, sq, sfull);
+    if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    return project_forward<DEPTH>(full, sfull, in2, count, out, batch, h, w, fillhole, so, s2, sc, st);
+}
+
 extern "C" int vfi_flowprojection_forward_up4(const float* flow_q, float* count, float* output, int batch, int hq, int wq,
                                                float mul0, float mul1, int fillhole, vfi_strides sq, vfi_strides sc,
                                                vfi_strides so, vfi_stream_t stream) {
     if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !count || !output)
         return VFI_ERR_SHAPE;
-    return project_forward<false, true>(flow_q, sq, hq, wq, mul0, mul1, nullptr, count, output, batch, 4 * hq, 4 * wq, fillhole,
-                                        so, so, sc, (hipStream_t)stream);
+    return project_forward_up4<false>(flow_q, sq, hq, wq, mul0, mul1, nullptr, count, output, batch, fillhole, so, so, sc,
+                                      (hipStream_t)stream);
 }
 
 extern "C" int vfi_depthflowprojection_forward_up4(const float* flow_q, const float* input2, float* count, float* output,
@@ -1771,8 +1758,8 @@ extern "C" int vfi_depthflowprojection_forward_up4(const float* flow_q, const fl
                                                     vfi_stream_t stream) {
     if (batch <= 0 || hq <= 0 || wq <= 0 || hq > INT_MAX / 4 || wq > INT_MAX / 4 || !flow_q || !input2 || !count || !output)
         return VFI_ERR_SHAPE;
-    return project_forward<true, true>(flow_q, sq, hq, wq, mul0, mul1, input2, count, output, batch, 4 * hq, 4 * wq, fillhole,
-                                       so, s2, sc, (hipStream_t)stream);
+    return project_forward_up4<true>(flow_q, sq, hq, wq, mul0, mul1, input2, count, output, batch, fillhole, so, s2, sc,
+                                     (hipStream_t)stream);
 }
 
 extern "C" int vfi_flowprojection_backward(const float* input1, const float* count, const float* gradoutput,

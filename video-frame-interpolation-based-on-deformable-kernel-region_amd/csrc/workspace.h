@@ -19,6 +19,7 @@ enum WsSlot {
     WS_PROJ_WORDS = 0,      // projection: header, super-tile and block tables, per-tile hole counts
     WS_PROJ_BITS,           // projection: row- and column-packed bitmaps of "count != 0"
     WS_PROJ_PLANES,         // projection fallback: three dense fp32 planes, zero between calls
+    WS_PROJ_UPFLOW,         // *_forward_up4: the upsampled full-resolution flow (pure scratch)
     WS_MINDEPTH,            // MinDepthFlowProjection: 64-bit keys + bitmaps
     WS_GRADACC,             // backward passes: 64-bit fixed-point image-gradient sums (vfi_common.h: gradacc_*)
     WS_SLOTS

@@ -26,7 +26,8 @@ def forward_flownets_upsample(flow_q, div_flow, time_offsets):
 
 
 def FlowProject_from_quarter(flow_q, div_flow, time_offsets, depth=None, fillhole=True):
-    """`forward_flownets` + `FlowProject` (inference: fillhole) without the full-resolution flows in between."""
+    """`forward_flownets` + `FlowProject` (inference: fillhole) in one call per time offset: the full-resolution flow lives in
+    a scratch tensor of the library, not in a tensor of the caller."""
     b, _, hq, wq = flow_q.shape
     outs = []
     for t in time_offsets:
