@@ -216,17 +216,18 @@ def test_deformable_forward_bit_exact(torch_mod, cabi, oracle, variant, fs):
         assert np.array_equal(cpu(out), ref)
 
 
-def test_deformable_fast_kernel_equals_general(torch_mod, cabi, oracle):
-    """fs == 4 runs fi_forward_defor4 (tap geometry hoisted out of the channel loop); the general kernel is kept for
-    other sizes.  Same bits, on frames with taps leaving the image on every side and large learned offsets."""
+@pytest.mark.parametrize("fs", [4, 6])
+def test_deformable_fast_kernel_equals_general(torch_mod, cabi, oracle, fs):
+    """fs == 4 and fs == 6 (the sizes the reference's 4-input kernel has bodies for) run the LDS-staged kernel; the general
+    one-thread-per-pixel kernel is kept for other sizes.  Same bits, on frames with taps leaving the image on every side and
+    large learned offsets (the last case: windows that do not fit the LDS, the staged kernel's own gather fallback)."""
     torch = torch_mod
-    import ctypes
-    rng = np.random.default_rng(41)
-    for (B, C, H, W, sig, osig) in ((2, 5, 37, 70, 3.0, 0.7), (1, 9, 64, 130, 8.0, 3.0), (1, 3, 8, 9, 1.0, 6.0)):
+    rng = np.random.default_rng(41 + fs)
+    for (B, C, H, W, sig, osig) in ((2, 5, 37, 70, 3.0, 0.7), (1, 9, 64, 130, 8.0, 3.0), (1, 3, 8, 9, 1.0, 6.0), (1, 2, 40, 200, 2.0, 40.0)):
         img = rng.standard_normal((B, C, H, W)).astype(f32)
         flow = smooth_flow(rng, B, H, W, sig) if min(H, W) >= 16 else (rng.standard_normal((B, 2, H, W)) * sig).astype(f32)
-        filt = rng.random((B, 16, H, W), dtype=f32)
-        off = (rng.standard_normal((B, 32, H, W)) * osig).astype(f32)
+        filt = rng.random((B, fs * fs, H, W), dtype=f32)
+        off = (rng.standard_normal((B, 2 * fs * fs, H, W)) * osig).astype(f32)
         for variant in (0, 1, 2):
             third = off if variant == 2 else filt
             outs = []

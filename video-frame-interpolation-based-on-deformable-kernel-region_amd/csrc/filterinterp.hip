@@ -422,7 +422,7 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
 
 extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* input1, const float* input2,
                                                    const float* input3, const float* input4, float* output,
-                                                   int batch, int channel, int h, int w,
+                                                   int batch, int channel, int h, int w, int filter_size,
                                                    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
                                                    vfi_stream_t stream);
 
@@ -436,10 +436,10 @@ static int defor_forward(bool allow_staged, int variant, const float* input1, co
     if (variant != VFI_DEFOR_NOFILTER && !input4) return VFI_ERR_SHAPE;
     const dim3 grid = pixel_grid(w, h, batch), block(VFI_TX, VFI_TY, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (filter_size == 4 && allow_staged && variant >= 0 && variant <= 2) {
+    if ((filter_size == 4 || filter_size == 6) && allow_staged && variant >= 0 && variant <= 2) {
         // LDS-staged kernel (filterinterp_defor_lds.hip); -1 = not applicable
         const int err = vfi_filterinterp_forward_defor_lds(variant, input1, input2, input3, input4, output, batch,
-                                                           channel, h, w, s1, s2, s3, s4, stream);
+                                                           channel, h, w, filter_size, s1, s2, s3, s4, stream);
         if (err >= 0) return err;
     }
     switch (variant) {

@@ -1,4 +1,5 @@
-// filterinterp_defor_lds.hip -- LDS-staged forward of the deformable FilterInterpolation variants, fs == 4.
+// filterinterp_defor_lds.hip -- LDS-staged forward of the deformable FilterInterpolation variants, fs == 4 and fs == 6
+// (the two sizes the reference's 4-input kernel has bodies for, filterinterpolation_cuda_kernel.cu:68).
 //
 // Semantics: filterinterpolation_cuda_kernel.cu:29-426 (4-input forward, VARIANT 0), :1353-1496
 // (deforconv = the paper's deformable kernel region, VARIANT 1), :2070-2191 (nofilterwithdeforconv,
@@ -17,7 +18,8 @@
 // bilinear fractions, the filter weight, and its quadrant.
 //
 // A tile whose window does not fit the LDS budget (large learned offsets) gathers from global memory instead,
-// decided per workgroup; other filter sizes use fi_forward_defor.
+// decided per workgroup; other filter sizes use fi_forward_defor.  fs == 6 keeps 36 taps x (corner index, two fractions,
+// weight) = 144 registers per pixel: one workgroup per CU (at 256 registers the region variant spills inside its pipeline).
 #include "filterinterp_dev.h"
 
 #include <limits.h>
@@ -49,18 +51,19 @@ struct DfWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
 // One pixel's state for the channel loop.  lb[k]: float index, inside a staged window, of tap k's top-left
 // corner; phy / phx: the fractions of defor_tap; qx / qy bit k: the tap lies right of / below the sampling
 // position (VARIANT 1, 2).
-struct DfPixel {
+template <int FS> struct DfPixel {
     bool valid, inimg;
     float alpha, beta;
-    unsigned pix, qx, qy;
-    int lb[16];
-    float phy[16], phx[16], wgt[16];
+    unsigned pix;
+    unsigned long long qx, qy;
+    int lb[FS * FS];
+    float phy[FS * FS], phx[FS * FS], wgt[FS * FS];
 };
 
 // one tap: bilinear sample from its four corners (defor_tap's arithmetic, filterinterp.hip), then the
 // quadrant sum it belongs to
-template <int VARIANT, int KTAP>
-__device__ __forceinline__ void df_tap(const DfPixel& px, float a, float b, float c, float d, float (&q)[4]) {
+template <int VARIANT, int FS, int KTAP>
+__device__ __forceinline__ void df_tap(const DfPixel<FS>& px, float a, float b, float c, float d, float (&q)[4]) {
     float phiY = px.phy[KTAP], phiX = px.phx[KTAP];
     // keep the four corner weights out of the registers: left alone, the compiler hoists all 64 of them (and
     // the 16 second-row addresses) out of the channel loop and spills hundreds of registers
@@ -70,13 +73,13 @@ __device__ __forceinline__ void df_tap(const DfPixel& px, float a, float b, floa
     v = fmaf((1.0f - phiX) * phiY, c, v);
     v = fmaf(phiY * phiX, d, v);
     if constexpr (VARIANT == VFI_DEFOR_OFFSET) {
-        constexpr int quad = ((KTAP / 4) >= 2 ? 2 : 0) + ((KTAP % 4) >= 2 ? 1 : 0);     // by integer index
+        constexpr int quad = ((KTAP / FS) >= FS / 2 ? 2 : 0) + ((KTAP % FS) >= FS / 2 ? 1 : 0);     // by integer index
         q[quad] = fmaf(v, px.wgt[KTAP], q[quad]);
     } else {
         // by displaced position.  The quadrant number is re-extracted from the packed bits per channel: hoisted,
         // the 64 loop-invariant lane masks (16 taps x 4 quadrants) overflow the scalar registers and come back as
         // hundreds of v_readlane / v_writelane
-        unsigned code = ((px.qx >> KTAP) & 1u) | (((px.qy >> KTAP) & 1u) << 1);
+        unsigned code = (unsigned)((px.qx >> KTAP) & 1ull) | ((unsigned)((px.qy >> KTAP) & 1ull) << 1);
         asm volatile("" : "+v"(code));
 #pragma unroll
         for (int quad = 0; quad < 4; ++quad) {
@@ -87,32 +90,36 @@ __device__ __forceinline__ void df_tap(const DfPixel& px, float a, float b, floa
     }
 }
 
-// a row of four taps: its 16 values are fetched (F: tap index -> the four corner values) before they are used
-template <int VARIANT, int J, typename F>
-__device__ __forceinline__ void df_tap_row(const DfPixel& px, F&& fetch, float (&q)[4]) {
-    float v[4][4];
+// a row of FS taps: its 4 FS corner values are fetched (F: tap index -> the four corner values) before they are used
+template <int VARIANT, int FS, int J, int I, typename V>
+__device__ __forceinline__ void df_tap_row_taps(const DfPixel<FS>& px, const V& v, float (&q)[4]) {
+    if constexpr (I < FS) {
+        df_tap<VARIANT, FS, J * FS + I>(px, v[I][0], v[I][1], v[I][2], v[I][3], q);
+        df_tap_row_taps<VARIANT, FS, J, I + 1>(px, v, q);
+    }
+}
+template <int VARIANT, int FS, int J, typename F>
+__device__ __forceinline__ void df_tap_rows(const DfPixel<FS>& px, F&& fetch, float (&q)[4]) {
+    if constexpr (J < FS) {
+        float v[FS][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fetch(J * 4 + i, v[i]);
-    df_tap<VARIANT, J * 4 + 0>(px, v[0][0], v[0][1], v[0][2], v[0][3], q);
-    df_tap<VARIANT, J * 4 + 1>(px, v[1][0], v[1][1], v[1][2], v[1][3], q);
-    df_tap<VARIANT, J * 4 + 2>(px, v[2][0], v[2][1], v[2][2], v[2][3], q);
-    df_tap<VARIANT, J * 4 + 3>(px, v[3][0], v[3][1], v[3][2], v[3][3], q);
+        for (int i = 0; i < FS; ++i) fetch(J * FS + i, v[i]);
+        df_tap_row_taps<VARIANT, FS, J, 0>(px, v, q);
+        df_tap_rows<VARIANT, FS, J + 1>(px, fetch, q);
+    }
 }
 
-template <int VARIANT, typename F>
-__device__ __forceinline__ float df_value(const DfPixel& px, F&& fetch) {
+template <int VARIANT, int FS, typename F>
+__device__ __forceinline__ float df_value(const DfPixel<FS>& px, F&& fetch) {
     float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};                  // TL, TR, BL, BR
-    df_tap_row<VARIANT, 0>(px, fetch, q);
-    df_tap_row<VARIANT, 1>(px, fetch, q);
-    df_tap_row<VARIANT, 2>(px, fetch, q);
-    df_tap_row<VARIANT, 3>(px, fetch, q);
+    df_tap_rows<VARIANT, FS, 0>(px, fetch, q);
     return blend4(px.alpha, px.beta, q[0], q[1], q[2], q[3]);
 }
 
-template <int VARIANT, int K>
+template <int VARIANT, int FS, int K>
 __device__ __forceinline__ void df_run_channels(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
                                                 int c_begin, int c_end, int tid, const DfWindow& win,
-                                                const DfPixel& px, float* __restrict__ ring, int R) {
+                                                const DfPixel<FS>& px, float* __restrict__ ring, int R) {
     static_assert(3 * K <= 63, "vmcnt is a 6-bit counter");
     // staging exactly as fi_run_channels (filterinterp_lds.hip): element e = tid + k * threads of the window,
     // row pitch a multiple of the 32 banks, pad elements get an out-of-range offset (no memory traffic)
@@ -139,7 +146,7 @@ __device__ __forceinline__ void df_run_channels(const float* __restrict__ img, f
         if (!px.valid) return;
         const float* base = ring + slot * NP;
         const int pitch = win.pitch;
-        out[(int64_t)c * cs + px.pix] = df_value<VARIANT>(px, [&](int k, float (&v)[4]) {
+        out[(int64_t)c * cs + px.pix] = df_value<VARIANT, FS>(px, [&](int k, float (&v)[4]) {
             int o = px.lb[k];
             asm volatile("" : "+v"(o));                     // (second-row address re-derived per channel, see df_tap)
             const float* t = base + o;
@@ -165,8 +172,8 @@ __device__ __forceinline__ void df_run_channels(const float* __restrict__ img, f
         for (int c = c_begin; c < c_end; ++c) out[(int64_t)c * cs + px.pix] = img[(int64_t)c * cs + px.pix];
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
+template <int VARIANT, int FS>
+__global__ __launch_bounds__(DF_THREADS, FS == 4 ? 3 : 1) void fi_forward_defor_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     const float* __restrict__ in4, float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
@@ -184,7 +191,8 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
     const int x = txi * DF_TW + (tid & (DF_TW - 1));
     const int y = tyi * DF_TH + (tid >> 6);
 
-    DfPixel px;
+    constexpr int NT = FS * FS;                             // taps
+    DfPixel<FS> px;
     px.inimg = x < w && y < h;
     px.pix = (unsigned)(y * (int)s1.h + x);
     float fx = 0.0f, fy = 0.0f;
@@ -197,13 +205,19 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
     const float y2 = (float)y + fy;
     px.valid = px.inimg && fi_valid(fx, fy, x2, y2, w, h);
     const int ix = px.valid ? (int)x2 : 0, iy = px.valid ? (int)y2 : 0;
-    const int L = ix - 1, T = iy - 1;                       // ix + 1 - fs / 2, fs == 4
+    const int L = ix + 1 - FS / 2, T = iy + 1 - FS / 2;
     px.alpha = x2 - (float)ix;
     px.beta = y2 - (float)iy;
-    px.qx = 0u; px.qy = 0u;
+    px.qx = 0ull; px.qy = 0ull;
 
-    // ---- the 16 displaced taps of this pixel
-    int tl[16], tt[16];                                     // top-left corner (window coordinates, before by0 / bx0)
+    // ---- the displaced taps of this pixel
+    // top-left corner of each tap (frame coordinates, from -1), row and column packed into one register: with 36 taps the
+    // two arrays beside the 3 x 36 per-tap constants do not fit the register file
+    constexpr bool PACKED = FS != 4;                        // (fs == 4 keeps them apart: packed, that kernel spills inside its pipeline)
+    unsigned tc[NT];
+    int tt4[PACKED ? 1 : NT], tl4[PACKED ? 1 : NT];
+    auto corner_y = [&](int k) { if constexpr (PACKED) return (int)(tc[k] >> 16) - 1; else return tt4[k]; };
+    auto corner_x = [&](int k) { if constexpr (PACKED) return (int)(tc[k] & 0xffffu) - 1; else return tl4[k]; };
     int bx_lo = INT_MAX, by_lo = INT_MAX, bx_hi = INT_MIN, by_hi = INT_MIN;
     if (px.valid) {
         // 32 (48) loads first.  Buffer form: a wave-uniform descriptor of this batch item's filter / offset tensor,
@@ -217,33 +231,37 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
         const unsigned ovo = (VARIANT == VFI_DEFOR_NOFILTER) ? fvo : 4u * (unsigned)(y * (int)s4.h + x);
         const unsigned ocs4 = 4u * (unsigned)((VARIANT == VFI_DEFOR_NOFILTER) ? s3.c : s4.c), fcs4 = 4u * (unsigned)s3.c;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < NT; ++k) {
             px.phy[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, ovo, k * ocs4, 0));
-            px.phx[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, ovo, (16 + k) * ocs4, 0));
+            px.phx[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, ovo, (NT + k) * ocs4, 0));
             px.wgt[k] = (VARIANT == VFI_DEFOR_NOFILTER)
                             ? 1.0f
                             : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frs, fvo, k * fcs4, 0));
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int cj = clampi(T + k / 4, 0, h - 1), ci = clampi(L + k % 4, 0, w - 1);
+        for (int k = 0; k < NT; ++k) {
+            const int cj = clampi(T + k / FS, 0, h - 1), ci = clampi(L + k % FS, 0, w - 1);
             const float fracY = (float)cj + px.phy[k];
             const float fracX = (float)ci + px.phx[k];
             const int Top = (int)fracY, Left = (int)fracX;
             px.phy[k] = fracY - (float)Top;
             px.phx[k] = fracX - (float)Left;
-            if (fracX > x2) px.qx |= 1u << k;
-            if (fracY > y2) px.qy |= 1u << k;
+            if (fracX > x2) px.qx |= 1ull << k;
+            if (fracY > y2) px.qy |= 1ull << k;
             // rows <= -1 all replicate row 0 and rows >= h - 1 row h - 1, so a corner pair starting at
             // clamp(Top, -1, h - 1) reads what clamp(Top), clamp(Top + 1) read: the window stays near the frame
-            tt[k] = clampi(Top, -1, h - 1);
-            tl[k] = clampi(Left, -1, w - 1);
-            bx_lo = min(bx_lo, tl[k]); by_lo = min(by_lo, tt[k]);
-            bx_hi = max(bx_hi, tl[k] + 1); by_hi = max(by_hi, tt[k] + 1);
+            const int tt = clampi(Top, -1, h - 1), tl = clampi(Left, -1, w - 1);
+            if constexpr (PACKED) tc[k] = ((unsigned)(tt + 1) << 16) | (unsigned)(tl + 1);
+            else { tt4[k] = tt; tl4[k] = tl; }
+            bx_lo = min(bx_lo, tl); by_lo = min(by_lo, tt);
+            bx_hi = max(bx_hi, tl + 1); by_hi = max(by_hi, tt + 1);
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { px.phy[k] = 0.0f; px.phx[k] = 0.0f; px.wgt[k] = 0.0f; tl[k] = 0; tt[k] = 0; }
+        for (int k = 0; k < NT; ++k) {
+            px.phy[k] = 0.0f; px.phx[k] = 0.0f; px.wgt[k] = 0.0f;
+            if constexpr (PACKED) tc[k] = 0x00010001u; else { tt4[k] = 0; tl4[k] = 0; }
+        }
     }
 
     // ---- bounding box of every corner of the tile
@@ -275,8 +293,8 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
             const int plane_bytes = 4 * ((h - 1) * hs + w);
             for (int c = c_begin; c < c_end; ++c) {
                 const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)c * s1.c), 0, plane_bytes, 0x00020000);
-                dst[(int64_t)c * s1.c + px.pix] = df_value<VARIANT>(px, [&](int k, float (&v)[4]) {
-                    int ty = tt[k], tx = tl[k];
+                dst[(int64_t)c * s1.c + px.pix] = df_value<VARIANT, FS>(px, [&](int k, float (&v)[4]) {
+                    int ty = corner_y(k), tx = corner_x(k);
                     asm volatile("" : "+v"(ty), "+v"(tx));  // corner addresses re-derived per channel, not hoisted (registers)
                     const int r0 = clampi(ty, 0, h - 1) * hs, r1 = clampi(ty + 1, 0, h - 1) * hs;
                     const int q0 = clampi(tx, 0, w - 1), q1 = clampi(tx + 1, 0, w - 1);
@@ -292,11 +310,11 @@ __global__ __launch_bounds__(DF_THREADS, 3) void fi_forward_defor_lds(
         return;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) px.lb[k] = (tt[k] - by0) * pitch + (tl[k] - bx0);
+    for (int k = 0; k < NT; ++k) px.lb[k] = (corner_y(k) - by0) * pitch + (corner_x(k) - bx0);
 
     const DfWindow win{bx0, by0, bw, bh, pitch, h, w, hs};
     float* ring = lds + DF_HDR;
-#define DF_RUN(K) df_run_channels<VARIANT, K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
+#define DF_RUN(K) df_run_channels<VARIANT, FS, K>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
                                               min(DF_RMAX, DF_RING_FLOATS / ((K) * DF_THREADS)))
     if (kmax <= 3) DF_RUN(3);
     else if (kmax == 4) DF_RUN(4);
@@ -316,20 +334,23 @@ using namespace vfi;
 // returns -1 when this path does not apply (the caller uses the direct kernels)
 extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* input1, const float* input2,
                                                    const float* input3, const float* input4, float* output,
-                                                   int batch, int channel, int h, int w,
+                                                   int batch, int channel, int h, int w, int filter_size,
                                                    vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4,
                                                    vfi_stream_t stream) {
+    if (filter_size != 4 && filter_size != 6) return -1;
+    if (h > 65534 || w > 65534) return -1;                   // (tap corners travel as two 16-bit halves)
+    const int nt = filter_size * filter_size;
     if ((int64_t)h * s1.h * 4 > INT_MAX) return -1;          // byte offsets inside a plane are 32-bit
     // the filter / offset tensors of one batch item are addressed through 32-bit buffer offsets (signed descriptor size)
-    const int nf = (variant == VFI_DEFOR_NOFILTER) ? 32 : 16;
+    const int nf = (variant == VFI_DEFOR_NOFILTER) ? 2 * nt : nt;
     const int64_t fb = 4 * ((int64_t)(nf - 1) * s3.c + (int64_t)(h - 1) * s3.h + w);
-    const int64_t ob = (variant == VFI_DEFOR_NOFILTER) ? fb : 4 * ((int64_t)31 * s4.c + (int64_t)(h - 1) * s4.h + w);
+    const int64_t ob = (variant == VFI_DEFOR_NOFILTER) ? fb : 4 * ((int64_t)(2 * nt - 1) * s4.c + (int64_t)(h - 1) * s4.h + w);
     if (fb > INT_MAX || ob > INT_MAX || s3.c < 0 || s3.h < 0 || s4.c < 0 || s4.h < 0) return -1;
     const unsigned filt_bytes = (unsigned)fb, off_bytes = (unsigned)ob;
     const int tiles_x = (w + DF_TW - 1) / DF_TW, tiles_y = (h + DF_TH - 1) / DF_TH;
-    const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
-    if (nt > INT_MAX) return -1;
-    const int ntiles = (int)nt;
+    const int64_t ntl = (int64_t)tiles_x * tiles_y * batch;
+    if (ntl > INT_MAX) return -1;
+    const int ntiles = (int)ntl;
     // (a channel of these kernels costs ~4x one of the _ori kernel, the prologue -- flow, offsets, filter: up to 200 B/pixel --
     //  ~3x: about 3 channels' worth)
     const int best_groups = fi_channel_groups(ntiles, channel, variant == VFI_DEFOR_NOFILTER ? 2.0 : 3.0);
@@ -337,21 +358,21 @@ extern "C" int vfi_filterinterp_forward_defor_lds(int variant, const float* inpu
     const int groups = (channel + ch_per_group - 1) / ch_per_group;
     const dim3 grid((unsigned)ntiles, (unsigned)groups, 1), block(DF_THREADS, 1, 1);
     hipStream_t st = (hipStream_t)stream;
+#define DF_LAUNCH(V, FSZ, IN4, S4, OB) hipLaunchKernelGGL((fi_forward_defor_lds<V, FSZ>), grid, block, 0, st, input1, input2, input3, IN4, \
+                           output, channel, h, w, s1, s2, s3, S4, tiles_x, tiles_y, ntiles, ch_per_group, filt_bytes, OB)
     switch (variant) {
     case VFI_DEFOR_OFFSET:
-        hipLaunchKernelGGL(fi_forward_defor_lds<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
-                           output, channel, h, w, s1, s2, s3, s4, tiles_x, tiles_y, ntiles, ch_per_group, filt_bytes, off_bytes);
+        if (filter_size == 4) DF_LAUNCH(VFI_DEFOR_OFFSET, 4, input4, s4, off_bytes); else DF_LAUNCH(VFI_DEFOR_OFFSET, 6, input4, s4, off_bytes);
         break;
     case VFI_DEFOR_REGION:
-        hipLaunchKernelGGL(fi_forward_defor_lds<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
-                           output, channel, h, w, s1, s2, s3, s4, tiles_x, tiles_y, ntiles, ch_per_group, filt_bytes, off_bytes);
+        if (filter_size == 4) DF_LAUNCH(VFI_DEFOR_REGION, 4, input4, s4, off_bytes); else DF_LAUNCH(VFI_DEFOR_REGION, 6, input4, s4, off_bytes);
         break;
     case VFI_DEFOR_NOFILTER:
-        hipLaunchKernelGGL(fi_forward_defor_lds<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3, input3,
-                           output, channel, h, w, s1, s2, s3, s3, tiles_x, tiles_y, ntiles, ch_per_group, filt_bytes, filt_bytes);
+        if (filter_size == 4) DF_LAUNCH(VFI_DEFOR_NOFILTER, 4, input3, s3, filt_bytes); else DF_LAUNCH(VFI_DEFOR_NOFILTER, 6, input3, s3, filt_bytes);
         break;
     default:
         return -1;
     }
+#undef DF_LAUNCH
     return launch_status();
 }
