@@ -678,7 +678,10 @@ def test_correlation_forward(torch_mod, cabi, oracle, C, H, W, pad, k, md, s1, s
 def test_correlation_backward(torch_mod, cabi, oracle):
     torch = torch_mod
     rng = np.random.default_rng(61)
-    for (C, H, W, pad, k, md, s2) in ((6, 9, 33, 4, 1, 4, 1), (3, 8, 8, 4, 3, 4, 2)):
+    # (pad 4, k 1, md 4, strides 1 = PWC-Net's configuration: the pixel-owns-its-gradOutput kernel, incl. ragged tiles, several
+    #  channel groups and frames smaller than the halo; anything else: the one-thread-per-element kernel)
+    for (C, H, W, pad, k, md, s2) in ((6, 9, 33, 4, 1, 4, 1), (3, 8, 8, 4, 3, 4, 2), (32, 36, 62, 4, 1, 4, 1), (5, 70, 130, 4, 1, 4, 1),
+                                      (2, 3, 2, 4, 1, 4, 1), (4, 12, 20, 3, 1, 4, 1)):
         f1 = rng.normal(size=(2, C, H, W)).astype(f32)
         f2 = rng.normal(size=(2, C, H, W)).astype(f32)
         oc, oh, ow = oracle.correlation_out_dims(H, W, pad, k, md, 1, s2)

@@ -19,6 +19,8 @@
 // workgroup, 9 running sums per lane), which spreads the same work over 9x more waves.
 #include "vfi_common.h"
 
+#include <algorithm>
+
 #include <hip/hip_fp16.h>
 
 namespace vfi {
@@ -734,6 +736,70 @@ __global__ __launch_bounds__(256) void corr_backward(
     }
 }
 
+// Backward for PWC-Net's configuration (k == 1, strides 1, pad == md == 4; round 3).  corr_backward above is one thread per
+// gradient element: 81 loads of gradOutput + 81 of the other map + 81 multiply-adds each, and a gradOutput element is
+// fetched again by every channel (1.1 ms for both gradients at 32 x 288 x 496).  Here a thread owns one PIXEL: its 81
+// gradOutput values (gradInput1: the 81 planes at the pixel; gradInput2: plane tc at the pixel moved back by displacement
+// tc) live in registers for all channels, and per channel the workgroup (64x4 pixels) stages the other map's window
+// (tile + 4 halo, zero padded) in LDS, double-buffered.  The sum runs in the reference's order -- 32 partial sums over
+// tc = l, l + 32, l + 64, added in sequence (correlation_cuda_kernel.cu:162-239, 255-332) -- so the result is corr_backward's
+// and the oracle's bit for bit.
+template <bool SECOND>
+__global__ __launch_bounds__(256) void corr_backward_k1(
+    const float* __restrict__ other, const float* __restrict__ gout, float* __restrict__ gin,
+    int channel, int h, int w, int groups, int ch_per_group) {
+    constexpr int MD = 4, D = 2 * MD + 1, OC = D * D, TW = 64, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;
+    __shared__ float win[2][LH][LW];
+    const int tid = threadIdx.x, px = tid & 63, py = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int bx = x0 + px, by = y0 + py;
+    const int n = blockIdx.z / groups, cg = blockIdx.z - n * groups;
+    const int c_begin = cg * ch_per_group, c_end = min(channel, c_begin + ch_per_group);
+    const bool in = bx < w && by < h;
+    const int64_t plane = (int64_t)h * w;
+    const float* go = gout + (int64_t)n * OC * plane;
+
+    // the pixel's 81 gradOutput values (zero where the reference skips the term: gradInput2 near the frame's border)
+    float g[OC];
+#pragma unroll
+    for (int tc = 0; tc < OC; ++tc) {
+        const int gy = SECOND ? by - (tc / D - MD) : by, gx = SECOND ? bx - (tc % D - MD) : bx;
+        g[tc] = (in && gy >= 0 && gy < h && gx >= 0 && gx < w) ? go[(int64_t)tc * plane + (int64_t)gy * w + gx] : 0.0f;
+    }
+    // (a term the reference skips -- gradInput2, displaced position outside the frame -- reads the other map at that same
+    //  position: the zero padding of the staged window, so the skipped term is fma(0, 0, s) = s)
+
+    auto stage = [&](int c, int buf) {
+        const float* of = other + ((int64_t)n * channel + c) * plane;
+        for (int e = tid; e < LH * LW; e += 256) {
+            const int r = e / LW, col = e - r * LW;
+            const int gy = y0 - MD + r, gx = x0 - MD + col;
+            win[buf][r][col] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? of[(int64_t)gy * w + gx] : 0.0f;
+        }
+    };
+    if (c_begin >= c_end) return;
+    stage(c_begin, 0);
+    const float nelems = (float)channel;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        __syncthreads();                                    // window c has been written; window c - 1 has been read
+        if (c + 1 < c_end) stage(c + 1, buf ^ 1);
+        float r = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) {
+            float s = 0.0f;
+#pragma unroll
+            for (int tc = l; tc < OC; tc += 32) {
+                const int tj = tc / D, ti = tc % D;
+                const float v = SECOND ? win[buf][py + 2 * MD - tj][px + 2 * MD - ti] : win[buf][py + tj][px + ti];
+                s = fmaf(g[tc], v, s);
+            }
+            r += s;
+        }
+        if (in) gin[((int64_t)n * channel + c) * plane + (int64_t)by * w + bx] = r / nelems;
+    }
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -859,6 +925,20 @@ extern "C" int vfi_correlation_backward(const float* input1, const float* input2
     if (stride1 != 1 || oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
+    if (kernel_size == 1 && stride2 == 1 && max_displacement == 4 && pad_size == 4) {
+        // PWC-Net's configuration: the pixel-owns-its-gradOutput kernel; channel groups over blockIdx.z fill the chip
+        const int tiles = ((w + 63) / 64) * ((h + 3) / 4);
+        int groups = (int)std::min<int64_t>(channel, std::max<int64_t>(1, (2048 + (int64_t)tiles * batch - 1) / ((int64_t)tiles * batch)));
+        const int ch_per_group = (channel + groups - 1) / groups;
+        groups = (channel + ch_per_group - 1) / ch_per_group;
+        if ((int64_t)batch * groups <= 65535) {
+            const dim3 grid((w + 63) / 64, (h + 3) / 4, batch * groups);
+            hipLaunchKernelGGL(corr_backward_k1<false>, grid, dim3(256), 0, st, input2, gradoutput, gradinput1, channel, h, w, groups, ch_per_group);
+            if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+            hipLaunchKernelGGL(corr_backward_k1<true>, grid, dim3(256), 0, st, input1, gradoutput, gradinput2, channel, h, w, groups, ch_per_group);
+            return launch_status();
+        }
+    }
     const int64_t total = (int64_t)batch * channel * h * w;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipLaunchKernelGGL(corr_backward<false>, grid, block, 0, st, input2, gradoutput, gradinput1, batch, channel, h, w,
