@@ -62,14 +62,28 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 
 // ------------------------------------------------------------------ backward, _ori
 
+// tile of fi_backward_ori4_lds (below)
+#define FB_TW 64
+#ifndef FB_TH
+#define FB_TH 8
+#endif
+#ifndef FB_WAVES
+#define FB_WAVES 1                                  // (launch bound: waves per SIMD the kernel must fit)
+#endif
+#define FB_THREADS (FB_TW * FB_TH)
+#define FB_CH 3                                     // channels summed per pass
+#define FB_CELLS 7168                               // 64-bit cells of LDS (57,344 bytes)
+
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g1, float* g2, float* g3,
-    int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
+    int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, const int* __restrict__ tileflag) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    // (after fi_backward_ori4_lds: only the tiles that kernel left alone; VFI_TX x VFI_TY blocks nest in them)
+    if (tileflag && !tileflag[(b * ((h + FB_TH - 1) / FB_TH) + y / FB_TH) * gridDim.x + blockIdx.x]) return;
     const GradAccCtx gctx = gradacc_ctx(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
@@ -132,6 +146,138 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     gf[0] = gx;
     gf[s2.c] = gy;
+}
+
+// fs == 4, image gradient through LDS (round 3).  The scatter above costs 16 global 64-bit atomics per pixel and channel
+// (110 M of them at 1080p, C = 3: 2 ms).  The addends are exact integers, so they can be summed in any grouping: a
+// workgroup of 1024 threads owns a 64x16 tile, takes the bounding box of its pixels' (clamped) taps and sums its addends
+// in a window of 64-bit cells in LDS (cheap integer atomics), three channels at a time; the window then goes to the
+// per-call scratch plane with ONE global atomic per non-zero cell -- (64 + 12) x (16 + 12) cells instead of 1024 x 16
+// addends per tile and channel.  Same integer sums, hence the same bits as the per-tap scatter; the 16 filter taps and the
+// 16 filter-gradient sums of the pixel live in registers across the channel loop (the general kernel re-reads the taps
+// and read-modify-writes the gradient cells in global memory once per channel and tap), summed in the same order from
+// the same starting value: the general kernel's bits.  A call with non-finite inputs (fp32 atomics: vfi_common.h) and a tile whose window does not fit keep the
+// per-tap scatter: the kernel flags them and fi_backward_ori, launched after it, does those tiles only.
+
+__global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
+    const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, int* __restrict__ tileflag,
+    float* g2, float* g3, int channel, int h, int w, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
+    constexpr int fs = 4;
+    __shared__ unsigned long long cells[FB_CELLS];
+    __shared__ int box[4];
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * FB_TW + (tid & (FB_TW - 1));
+    const int y = blockIdx.y * FB_TH + (tid >> 6);
+    const int b = blockIdx.z;
+    const GradAccCtx gctx = gradacc_ctx(hdr);
+    const bool inimg = x < w && y < h;
+    float fx = 0.0f, fy = 0.0f;
+    if (inimg) {
+        const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        fx = flow[0];
+        fy = flow[s2.c];
+    }
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    const bool valid = inimg && fi_valid(fx, fy, x2, y2, w, h);     // an invalid pixel has no gradient (:2863-2864)
+    const int ix = valid ? (int)x2 : 0, iy = valid ? (int)y2 : 0;
+    const int L = ix - 1, T = iy - 1;
+    const float alpha = x2 - (float)ix;
+    const float beta = y2 - (float)iy;
+    int ro[4], co[4];                                       // clamped rows and columns of the pixel's window
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ro[k] = clampi(T + k, 0, h - 1); co[k] = clampi(L + k, 0, w - 1); }
+    // ---- bounding box of the tile's (clamped) taps
+    if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
+    __syncthreads();
+    {
+        const int wx0 = wave_min_i32(valid ? co[0] : INT_MAX), wy0 = wave_min_i32(valid ? ro[0] : INT_MAX);
+        const int wx1 = wave_max_i32(valid ? co[3] : INT_MIN), wy1 = wave_max_i32(valid ? ro[3] : INT_MIN);
+        if ((tid & 63) == 0 && wx0 != INT_MAX) {
+            atomicMin(&box[0], wx0); atomicMin(&box[1], wy0);
+            atomicMax(&box[2], wx1); atomicMax(&box[3], wy1);
+        }
+    }
+    __syncthreads();
+    const bool any = box[0] != INT_MAX;
+    if (!any) return;                                       // (workgroup-uniform: nothing in this tile has a gradient)
+    const int bx0 = box[0], by0 = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
+    const int n = bw * bh;
+    if (gctx.nonfinite || n * min(FB_CH, channel) > FB_CELLS) {     // (workgroup-uniform) left to fi_backward_ori
+        if (tid == 0) tileflag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
+        return;
+    }
+
+    const float* img = in1 + (int64_t)b * s1.b;
+    unsigned long long* gimg = acc + (int64_t)b * channel * h * w;       // dense [b][c][y][x] fixed-point sums
+    const float* fpx = in3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    float* gfpx = g3 + (int64_t)b * s3.b + (int64_t)y * s3.h + x;
+    const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    float fv[16], gf16[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { fv[k] = valid ? fpx[(int64_t)k * s3.c] : 0.0f; gf16[k] = valid ? gfpx[(int64_t)k * s3.c] : 0.0f; }
+    int lrow[4];                                            // the window rows' first cells, less the box's first column
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lrow[k] = (ro[k] - by0) * bw - bx0;
+    float gx = 0.0f, gy = 0.0f;
+    for (int c0 = 0; c0 < channel; c0 += FB_CH) {
+        const int cn = min(FB_CH, channel - c0);
+        for (int e = tid; e < n * cn; e += FB_THREADS) cells[e] = 0ull;
+        __syncthreads();
+        for (int cc = 0; cc < cn; ++cc) {
+            const int c = c0 + cc;
+            if (!valid) continue;
+            const float* p = img + (int64_t)c * s1.c;
+            const float g = gpx[(int64_t)c * s1.c];
+            const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
+                                  g * (1.0f - alpha) * beta,          g * alpha * beta };
+            float pv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pv[k] = p[(int64_t)ro[k >> 2] * s1.h + co[k & 3]];
+            float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int quad = 0; quad < 4; ++quad)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int j = (quad >> 1) * 2 + jj, i = (quad & 1) * 2 + ii, k = j * fs + i;
+                        atomicAdd(&cells[cc * n + lrow[j] + co[i]], (unsigned long long)__float2ll_rn(qg[quad] * fv[k] * gctx.scale));
+                        gf16[k] += qg[quad] * pv[k];
+                        q[quad] = fmaf(pv[k], fv[k], q[quad]);
+                    }
+            {   // flow gradient by quadrant differences (:2965-3102)
+                const float gamma = 1.0f - beta;
+                float temp = gamma * (q[1] - q[0]);
+                temp = fmaf(1.0f - gamma, q[3] - q[2], temp);
+                gx = fmaf(g, temp, gx);
+            }
+            {
+                const float gamma = 1.0f - alpha;
+                float temp = gamma * (q[2] - q[0]);
+                temp = fmaf(1.0f - gamma, q[3] - q[1], temp);
+                gy = fmaf(g, temp, gy);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < n * cn; e += FB_THREADS) {
+            const unsigned long long v = cells[e];
+            if (v != 0ull) {
+                const int cc = e / n, r = e - cc * n;
+                const int cy = r / bw, cx = r - cy * bw;
+                atomicAdd(&gimg[(int64_t)(c0 + cc) * h * w + (int64_t)(by0 + cy) * w + bx0 + cx], v);
+            }
+        }
+        __syncthreads();                                    // (the next pass zeroes the cells)
+    }
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gfpx[(int64_t)k * s3.c] = gf16[k];
+        float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        gf[0] = gx;
+        gf[s2.c] = gy;
+    }
 }
 
 // ------------------------------------------------------------------ forward, deformable variants
@@ -411,11 +557,19 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
     const int fs = fi_filter_size(filter_channels);
     unsigned long long* acc;
     int* hdr;
-    int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, input3, filter_channels, s3, &acc, &hdr);
+    int* flags = nullptr;                                   // one word per 64x16 tile: "the staged kernel left it alone"
+    const int ntiles = ((w + FB_TW - 1) / FB_TW) * ((h + FB_TH - 1) / FB_TH) * batch;
+    int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, input3, filter_channels, s3, &acc, &hdr,
+                            fs == 4 ? ntiles : 0, &flags);
     if (err != VFI_OK) return err;
+    static_assert(VFI_TX == FB_TW && FB_TH % VFI_TY == 0, "fi_backward_ori's blocks nest in the staged kernel's tiles");
+    if (fs == 4)
+        hipLaunchKernelGGL(fi_backward_ori4_lds, dim3((w + FB_TW - 1) / FB_TW, (h + FB_TH - 1) / FB_TH, batch), dim3(FB_THREADS), 0,
+                           (hipStream_t)stream, input1, input2, input3, gradoutput, acc, hdr, flags, gradinput2, gradinput3,
+                           channel, h, w, s1, s2, s3);
     hipLaunchKernelGGL(fi_backward_ori, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
                        input1, input2, input3, gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3,
-                       channel, h, w, fs, s1, s2, s3);
+                       channel, h, w, fs, s1, s2, s3, fs == 4 ? flags : nullptr);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }

@@ -118,9 +118,11 @@ __device__ __forceinline__ void gradacc_add(unsigned long long* acc_plane, float
     if (cx.nonfinite) atomicAdd(&g_plane[gi], v);
     else atomicAdd(&acc_plane[di], (unsigned long long)__float2ll_rn(v * cx.scale));
 }
-// weights (may be null): a [batch, wchannel, h, w] tensor whose largest |element| bounds the tap weights
+// weights (may be null): a [batch, wchannel, h, w] tensor whose largest |element| bounds the tap weights;
+// nflags / flags: that many zeroed words of the same scratch for the caller's kernels (flags may be null)
 int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
-                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr);
+                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr,
+                  int nflags = 0, int** flags = nullptr);
 int gradacc_finish(hipStream_t st, const unsigned long long* acc, const int* hdr, float* g1, int batch, int channel, int h, int w,
                    vfi_strides s1);
 

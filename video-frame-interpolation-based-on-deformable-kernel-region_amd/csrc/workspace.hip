@@ -94,18 +94,33 @@ __global__ __launch_bounds__(256) void gradacc_max(const float* __restrict__ g, 
                                                    int* __restrict__ hdr, int slot, int cells_log2) {
     int m = 0;
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        const int c = (int)((i / ((int64_t)w * h)) % channel);
-        const int b = (int)(i / ((int64_t)w * h * channel));
-        const int bits = __float_as_int(fabsf(g[(int64_t)b * sg.b + (int64_t)c * sg.c + (int64_t)y * sg.h + x]));
-        bad = bad || bits >= 0x7f800000;                    // infinity or NaN
-        m = max(m, bits >= 0x7f800000 ? 0 : bits);
+    // a block per image row at a time: one set of divisions per row, consecutive lanes on consecutive elements
+    const int rows = (int)(n / w);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = row % h, bc = row / h;
+        const int c = bc % channel, b = bc / channel;
+        const float* p = g + (int64_t)b * sg.b + (int64_t)c * sg.c + (int64_t)y * sg.h;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const int bits = __float_as_int(fabsf(p[x]));
+            bad = bad || bits >= 0x7f800000;                // infinity or NaN
+            m = max(m, bits >= 0x7f800000 ? 0 : bits);
+        }
     }
+    // one atomic per block, and only from a block that raises the maximum: thousands of atomics on one word serialise
+    // in L2 (measured: 0.2 ms per pass when every wave issued its own)
+    __shared__ int wm[4], wbad[4];
     m = wave_max_i32(m);
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&hdr[slot], m);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&hdr[1], 1);
+    const bool anybad = __builtin_amdgcn_ballot_w64(bad) != 0ull;       // (all lanes active here)
+    if ((threadIdx.x & 63) == 0) {
+        wm[threadIdx.x >> 6] = m;
+        wbad[threadIdx.x >> 6] = anybad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m > __atomic_load_n(&hdr[slot], __ATOMIC_RELAXED)) atomicMax(&hdr[slot], m);
+        if ((wbad[0] | wbad[1] | wbad[2] | wbad[3]) && !__atomic_load_n(&hdr[1], __ATOMIC_RELAXED)) atomicOr(&hdr[1], 1);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && slot == 0) hdr[3] = cells_log2;
 }
 
@@ -113,33 +128,39 @@ __global__ __launch_bounds__(256) void gradacc_convert(const unsigned long long*
                                                        float* __restrict__ g1, int channel, int h, int w, vfi_strides s1, int64_t n) {
     if (hdr[1] != 0) return;                                // the call scattered with fp32 atomics: nothing in the scratch
     const int k = gradacc_exponent(hdr);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const long long sum = (long long)acc[i];
-        if (sum == 0) continue;
-        const int x = (int)(i % w);
-        const int y = (int)((i / w) % h);
-        const int c = (int)((i / ((int64_t)w * h)) % channel);
-        const int b = (int)(i / ((int64_t)w * h * channel));
-        float* cell = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h + x;
-        *cell += (float)ldexp((double)sum, -k);             // exact integer sum -> float once
+    const int rows = (int)(n / w);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = row % h, bc = row / h;
+        const int c = bc % channel, b = bc / channel;
+        const unsigned long long* a = acc + (int64_t)row * w;
+        float* cells = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c + (int64_t)y * s1.h;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const long long sum = (long long)a[x];
+            if (sum != 0) cells[x] += (float)ldexp((double)sum, -k);    // exact integer sum -> float once
+        }
     }
 }
 
 int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
-                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr) {
+                  const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr,
+                  int nflags, int** flags) {
     const int64_t n = (int64_t)batch * channel * h * w;
-    void* p = ws_get(st, WS_GRADACC, (size_t)n * 8 + 256, false, nullptr);
+    const size_t bytes = (size_t)n * 8 + 256 + (size_t)nflags * 4;
+    void* p = ws_get(st, WS_GRADACC, bytes, false, nullptr);
     if (!p) return VFI_ERR_LAUNCH;
-    if (hipMemsetAsync(p, 0, (size_t)n * 8 + 256, st) != hipSuccess) return VFI_ERR_LAUNCH;
+    if (hipMemsetAsync(p, 0, bytes, st) != hipSuccess) return VFI_ERR_LAUNCH;
     *hdr = static_cast<int*>(p);
     *acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 256);
+    if (flags) *flags = reinterpret_cast<int*>(static_cast<char*>(p) + 256 + (size_t)n * 8);
     int cells_log2 = 0;
     while (((int64_t)1 << cells_log2) < (int64_t)h * w) ++cells_log2;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    const int64_t rows = n / w;
+    const int blocks = (int)(rows < 2048 ? rows : 2048);
     hipLaunchKernelGGL(gradacc_max, dim3(blocks), dim3(256), 0, st, gout, channel, h, w, sg, n, *hdr, 0, cells_log2);
     if (weights) {
         const int64_t nw = (int64_t)batch * wchannel * h * w;
-        const int wblocks = (int)((nw + 255) / 256 < 4096 ? (nw + 255) / 256 : 4096);
+        const int64_t wrows = nw / w;
+        const int wblocks = (int)(wrows < 2048 ? wrows : 2048);
         hipLaunchKernelGGL(gradacc_max, dim3(wblocks), dim3(256), 0, st, weights, wchannel, h, w, sw, nw, *hdr, 2, cells_log2);
     }
     return launch_status();
@@ -148,7 +169,8 @@ int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int
 int gradacc_finish(hipStream_t st, const unsigned long long* acc, const int* hdr, float* g1, int batch, int channel, int h, int w,
                    vfi_strides s1) {
     const int64_t n = (int64_t)batch * channel * h * w;
-    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    const int64_t rows = n / w;
+    const int blocks = (int)(rows < 8192 ? rows : 8192);
     hipLaunchKernelGGL(gradacc_convert, dim3(blocks), dim3(256), 0, st, acc, hdr, g1, channel, h, w, s1, n);
     return launch_status();
 }
