@@ -533,6 +533,37 @@ def test_filterinterp_backward(torch_mod, cabi, oracle):
         assert torch.equal(g1, h1)
 
 
+def test_filterinterp_backward_staged_and_flagged_tiles(torch_mod, cabi, oracle):
+    """The fs=4 backward sums a tile's image-gradient addends in LDS when the tile's window fits and leaves the tile to the
+    per-tap kernel when it does not.  Left half of the image: smooth flow (staged tiles); right half: flows up to +-70 px
+    (windows far larger than the LDS budget, flagged tiles); C = 7 exercises the three-channel passes with a remainder,
+    non-zero starting gradients exercise the accumulate semantics (the reference adds into gradinput1 / gradinput3)."""
+    torch = torch_mod
+    rng = np.random.default_rng(35)
+    B, C, H, W, fs = 2, 7, 40, 200, 4
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    flow[:, :, :, W // 2:] = rng.uniform(-70, 70, size=(B, 2, H, W - W // 2)).astype(f32)
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    s1 = rng.normal(size=(B, C, H, W)).astype(f32)
+    s3 = rng.normal(size=(B, fs * fs, H, W)).astype(f32)
+    g1, g2, g3 = gpu(torch, s1), torch.zeros((B, 2, H, W), device="cuda:0"), gpu(torch, s3)
+    assert cabi.filterinterp_backward_ori(gpu(torch, img), gpu(torch, flow), gpu(torch, filt), gpu(torch, gout), g1, g2, g3) == 0
+    r1, r2, r3 = oracle.filterinterp_ori_bwd(img, flow, filt, gout, fmad=1)
+    assert np.abs(cpu(g1) - (s1 + r1)).max() <= GRAD_TOL * max(1.0, np.abs(r1).max())
+    assert np.array_equal(cpu(g2), r2)
+    # filter gradient: the kernel sums the channels in order starting from the cell's value, as the reference's += does
+    want3 = s3.copy()
+    for c in range(C):
+        want3 = want3 + oracle.filterinterp_ori_bwd(img[:, c:c + 1], flow, filt, gout[:, c:c + 1], fmad=1)[2]
+    assert np.array_equal(cpu(g3), want3)
+    h1 = gpu(torch, s1)
+    assert cabi.filterinterp_backward_ori(gpu(torch, img), gpu(torch, flow), gpu(torch, filt), gpu(torch, gout),
+                                          h1, torch.zeros_like(g2), gpu(torch, s3)) == 0
+    assert torch.equal(g1, h1)
+
+
 def test_image_gradient_nonfinite_and_large_inputs(torch_mod, cabi, oracle):
     """The fixed-point image gradient must not turn a NaN / Inf gradoutput into finite numbers (the reference's fp32
     atomics propagate it: divergence checks rely on that) and must not wrap on large filter values or many addends per
@@ -619,6 +650,28 @@ def test_interpolation_forward_backward(torch_mod, cabi, oracle):
     g1.zero_(), g2.zero_()
     assert cabi.interpolation_backward(gpu(torch, img), gpu(torch, fq), gpu(torch, gq), g1, g2) == 0
     assert np.array_equal(cpu(g1), oracle.interp_bwd(img, fq, gq, fmad=1)[0])
+
+
+def test_interpolation_backward_staged_and_flagged_tiles(torch_mod, cabi, oracle):
+    """Interpolation's backward sums a tile's image-gradient addends in LDS when the tile's window fits and leaves the tile
+    to the per-tap kernel when it does not: smooth flow on the left half (staged tiles), flows up to +-90 px on the right
+    (flagged tiles); C = 4 = one three-channel pass and a remainder; the image gradient adds into what gradinput1 holds."""
+    torch = torch_mod
+    rng = np.random.default_rng(43)
+    B, C, H, W = 2, 4, 36, 200
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 3.0)
+    flow[:, :, :, W // 2:] = rng.uniform(-90, 90, size=(B, 2, H, W - W // 2)).astype(f32)
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    s1 = rng.normal(size=(B, C, H, W)).astype(f32)
+    g1, g2 = gpu(torch, s1), torch.zeros((B, 2, H, W), device="cuda:0")
+    assert cabi.interpolation_backward(gpu(torch, img), gpu(torch, flow), gpu(torch, gout), g1, g2) == 0
+    r1, r2 = oracle.interp_bwd(img, flow, gout, fmad=1)
+    assert np.abs(cpu(g1) - (s1 + r1)).max() <= GRAD_TOL * max(1.0, np.abs(r1).max())
+    assert np.array_equal(cpu(g2), r2)
+    h1 = gpu(torch, s1)
+    assert cabi.interpolation_backward(gpu(torch, img), gpu(torch, flow), gpu(torch, gout), h1, torch.zeros_like(g2)) == 0
+    assert torch.equal(g1, h1)
 
 
 @pytest.mark.parametrize("fs", [1, 5, 13])

@@ -41,14 +41,23 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_forward(
     }
 }
 
+// tile of interp_backward_lds (below)
+#define IB_TW 64
+#define IB_TH 8
+#define IB_THREADS (IB_TW * IB_TH)
+#define IB_CH 3                                     // channels summed per pass
+#define IB_CELLS 6144                               // 64-bit cells of LDS (49,152 bytes)
+
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
     unsigned long long* __restrict__ acc, const int* __restrict__ hdr, float* g1, float* g2, int channel, int h, int w, vfi_strides s1,
-    vfi_strides s2) {
+    vfi_strides s2, const int* __restrict__ tileflag) {
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
     if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    // (after interp_backward_lds: only the tiles that kernel left alone; VFI_TX x VFI_TY blocks nest in them)
+    if (tileflag && !tileflag[(b * ((h + IB_TH - 1) / IB_TH) + y / IB_TH) * gridDim.x + blockIdx.x]) return;
     const GradAccCtx gctx = gradacc_ctx(hdr);
     const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     const float fx = flow[0];
@@ -87,6 +96,100 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void interp_backward(
     float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
     gf[0] = botx;
     gf[s2.c] = boty;
+}
+
+// The image gradient through LDS, as fi_backward_ori4_lds (filterinterp.hip) does it: the addends are exact integers, so a
+// 64x8 tile sums its 4 addends per pixel and channel in a window of 64-bit LDS cells over the bounding box of its taps,
+// three channels at a time, and issues one global atomic per non-zero cell.  Same integer sums as the per-tap scatter,
+// hence the same bits; flow gradient as in interp_backward.  A call with non-finite inputs and a tile whose window does
+// not fit are flagged and left to interp_backward, launched after this kernel.
+__global__ __launch_bounds__(IB_THREADS) void interp_backward_lds(
+    const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
+    unsigned long long* __restrict__ acc, const int* __restrict__ hdr, int* __restrict__ tileflag, float* g2,
+    int channel, int h, int w, vfi_strides s1, vfi_strides s2) {
+    __shared__ unsigned long long cells[IB_CELLS];
+    __shared__ int box[4];
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * IB_TW + (tid & (IB_TW - 1));
+    const int y = blockIdx.y * IB_TH + (tid >> 6);
+    const int b = blockIdx.z;
+    const GradAccCtx gctx = gradacc_ctx(hdr);
+    const bool inimg = x < w && y < h;
+    float fx = 0.0f, fy = 0.0f;
+    if (inimg) {
+        const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        fx = flow[0];
+        fy = flow[s2.c];
+    }
+    const float x2 = (float)x + fx;
+    const float y2 = (float)y + fy;
+    const bool valid = inimg && x2 >= 0.0f && y2 >= 0.0f && x2 < (float)w && y2 < (float)h;
+    const int L = valid ? (int)x2 : 0, T = valid ? (int)y2 : 0;
+    const int R = min(L + 1, w - 1), Bm = min(T + 1, h - 1);
+    if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
+    __syncthreads();
+    {
+        const int wx0 = wave_min_i32(valid ? L : INT_MAX), wy0 = wave_min_i32(valid ? T : INT_MAX);
+        const int wx1 = wave_max_i32(valid ? R : INT_MIN), wy1 = wave_max_i32(valid ? Bm : INT_MIN);
+        if ((tid & 63) == 0 && wx0 != INT_MAX) {
+            atomicMin(&box[0], wx0); atomicMin(&box[1], wy0);
+            atomicMax(&box[2], wx1); atomicMax(&box[3], wy1);
+        }
+    }
+    __syncthreads();
+    if (box[0] == INT_MAX) return;                          // (workgroup-uniform: nothing in this tile has a gradient)
+    const int bx0 = box[0], by0 = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
+    const int n = bw * bh;
+    if (gctx.nonfinite || n * min(IB_CH, channel) > IB_CELLS) {     // (workgroup-uniform) left to interp_backward
+        if (tid == 0) tileflag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
+        return;
+    }
+    const float alpha = x2 - (float)L, beta = y2 - (float)T;
+    const float* img = in1 + (int64_t)b * s1.b;
+    unsigned long long* gimg = acc + (int64_t)b * channel * h * w;
+    const float* gpx = gout + (int64_t)b * s1.b + (int64_t)y * s1.h + x;
+    const int64_t oT = (int64_t)T * s1.h, oB = (int64_t)Bm * s1.h;
+    const int cT = (T - by0) * bw - bx0, cB = (Bm - by0) * bw - bx0;       // window rows' first cells, less the box's first column
+    const float gam_y = (float)Bm - y2;         // (:161)
+    const float gam_x = (float)R - x2;          // (:181)
+    float botx = 0.0f, boty = 0.0f;
+    for (int c0 = 0; c0 < channel; c0 += IB_CH) {
+        const int cn = min(IB_CH, channel - c0);
+        for (int e = tid; e < n * cn; e += IB_THREADS) cells[e] = 0ull;
+        __syncthreads();
+        for (int cc = 0; cc < cn && valid; ++cc) {
+            const int c = c0 + cc;
+            const float* p = img + (int64_t)c * s1.c;
+            const float g = gpx[(int64_t)c * s1.c];
+            unsigned long long* win = cells + cc * n;
+            atomicAdd(&win[cT + L], (unsigned long long)__float2ll_rn(g * (1.0f - alpha) * (1.0f - beta) * gctx.scale));    // (:151-158)
+            atomicAdd(&win[cT + R], (unsigned long long)__float2ll_rn(g * alpha * (1.0f - beta) * gctx.scale));
+            atomicAdd(&win[cB + L], (unsigned long long)__float2ll_rn(g * (1.0f - alpha) * beta * gctx.scale));
+            atomicAdd(&win[cB + R], (unsigned long long)__float2ll_rn(g * alpha * beta * gctx.scale));
+            const float tl = p[oT + L], tr = p[oT + R], bl = p[oB + L], br = p[oB + R];
+            float temp = gam_y * (tr - tl);
+            temp = fmaf(1.0f - gam_y, br - bl, temp);
+            botx = fmaf(g, temp, botx);
+            temp = gam_x * (bl - tl);
+            temp = fmaf(1.0f - gam_x, br - tr, temp);
+            boty = fmaf(g, temp, boty);
+        }
+        __syncthreads();
+        for (int e = tid; e < n * cn; e += IB_THREADS) {
+            const unsigned long long v = cells[e];
+            if (v != 0ull) {
+                const int cc = e / n, r = e - cc * n;
+                const int cy = r / bw, cx = r - cy * bw;
+                atomicAdd(&gimg[(int64_t)(c0 + cc) * h * w + (int64_t)(by0 + cy) * w + bx0 + cx], v);
+            }
+        }
+        __syncthreads();                                    // (the next pass zeroes the cells)
+    }
+    if (valid) {
+        float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        gf[0] = botx;
+        gf[s2.c] = boty;
+    }
 }
 
 // ------------------------------------------------------------------ SeparableConv
@@ -280,10 +383,16 @@ extern "C" int vfi_interpolation_backward(const float* input1, const float* inpu
     unsigned long long* acc;
     int* hdr;
     // (the tap weights are bilinear fractions: at most 1)
-    const int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, nullptr, 0, s1, &acc, &hdr);
+    int* flags = nullptr;                                   // one word per 64x8 tile: "the staged kernel left it alone"
+    const dim3 tiles((w + IB_TW - 1) / IB_TW, (h + IB_TH - 1) / IB_TH, batch);
+    const int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, nullptr, 0, s1, &acc, &hdr,
+                                  (int)(tiles.x * tiles.y * tiles.z), &flags);
     if (err != VFI_OK) return err;
+    static_assert(VFI_TX == IB_TW && IB_TH % VFI_TY == 0, "interp_backward's blocks nest in the staged kernel's tiles");
+    hipLaunchKernelGGL(interp_backward_lds, tiles, dim3(IB_THREADS), 0, (hipStream_t)stream,
+                       input1, input2, gradoutput, acc, hdr, flags, gradinput2, channel, h, w, s1, s2);
     hipLaunchKernelGGL(interp_backward, pixel_grid(w, h, batch), dim3(VFI_TX, VFI_TY, 1), 0, (hipStream_t)stream,
-                       input1, input2, gradoutput, acc, hdr, gradinput1, gradinput2, channel, h, w, s1, s2);
+                       input1, input2, gradoutput, acc, hdr, gradinput1, gradinput2, channel, h, w, s1, s2, flags);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return gradacc_finish((hipStream_t)stream, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }
