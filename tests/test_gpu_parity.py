@@ -274,6 +274,40 @@ def test_deformable_backward(torch_mod, cabi, oracle, variant, fs):
         assert not cpu(go)[0, :, 3, 3].any() and not cpu(g2)[0, :, 3, 3].any()
 
 
+@pytest.mark.parametrize("variant,fs", [(0, 4), (1, 4), (2, 4), (1, 2)])
+def test_deformable_backward_staged_and_flagged_blocks(torch_mod, cabi, oracle, variant, fs):
+    """The deformable backward sums a 64x4 block's image-gradient addends in LDS when the block's window fits and leaves the
+    block to the per-tap instance when it does not: smooth flow on the left (staged), flows up to +-80 px on the right
+    (flagged); C = 4 = one three-channel pass and a remainder; every gradient adds into what its tensor holds (fs = 4 keeps
+    the filter / offset sums in registers across channels: same order, same bits)."""
+    torch = torch_mod
+    rng = np.random.default_rng(170 + 10 * variant + fs)
+    B, C, H, W = 1, 4, 24, 200
+    img = rng.random((B, C, H, W), dtype=f32)
+    flow = smooth_flow(rng, B, H, W, 2.0)
+    flow[:, :, :, W // 2:] = rng.uniform(-80, 80, size=(B, 2, H, W - W // 2)).astype(f32)
+    filt = rng.random((B, fs * fs, H, W), dtype=f32)
+    off = rng.uniform(-1.5, 1.5, (B, 2 * fs * fs, H, W)).astype(f32)
+    gout = rng.normal(size=(B, C, H, W)).astype(f32)
+    s1 = rng.normal(size=(B, C, H, W)).astype(f32)
+    g1, g2 = gpu(torch, s1), torch.zeros((B, 2, H, W), device="cuda:0")
+    go = torch.zeros((B, 2 * fs * fs, H, W), device="cuda:0")
+    if variant == 2:
+        err = cabi.filterinterp_backward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, off), None,
+                                               gpu(torch, gout), g1, g2, go, None)
+    else:
+        gf = torch.zeros((B, fs * fs, H, W), device="cuda:0")
+        err = cabi.filterinterp_backward_defor(variant, gpu(torch, img), gpu(torch, flow), gpu(torch, filt),
+                                               gpu(torch, off), gpu(torch, gout), g1, g2, gf, go)
+    assert err == 0
+    r1, r2, r3, r4 = oracle.filterinterp_defor_bwd(variant, img, flow, filt, off, gout, fmad=1)
+    assert np.abs(cpu(g1) - (s1 + r1)).max() <= GRAD_TOL * max(1.0, np.abs(r1).max())
+    assert np.array_equal(cpu(g2), r2)
+    assert np.array_equal(cpu(go), r4)
+    if variant != 2:
+        assert np.array_equal(cpu(gf), r3)
+
+
 # ------------------------------------------------------------------ fp16 storage (BASELINE configs[2], SURVEY 8d)
 
 def gpu16(torch, a):

@@ -33,3 +33,9 @@ g1, g2, g3 = torch.zeros_like(img), torch.zeros_like(flow), torch.zeros_like(fil
 print("filterinterp bwd ori C=3   %8.4f ms" % timed(lambda: cabi.filterinterp_backward_ori(img, flow, filt, gout, g1, g2, g3)), flush=True)
 gi, gf = torch.zeros_like(img), torch.zeros_like(flow)
 print("interpolation bwd C=3      %8.4f ms" % timed(lambda: cabi.interpolation_backward(img, flow, gout, gi, gf)), flush=True)
+# deformable kernel-region variants (fs = 4): offsets of a pixel or so
+off = (torch.rand((1, 32, H, W), generator=gen) * 2.0 - 1.0).cuda()
+go = torch.zeros_like(off)
+for variant, name in ((0, "offset"), (1, "region (deforconv)")):
+    print("defor bwd %-20s %8.4f ms" % (name, timed(lambda: cabi.filterinterp_backward_defor(variant, img, flow, filt, off, gout, g1, g2, g3, go), 5)), flush=True)
+print("defor fwd region C=3           %8.4f ms" % timed(lambda: cabi.filterinterp_forward_defor(1, img, flow, filt, off, g1)), flush=True)

@@ -9,7 +9,7 @@ PKG=$R/video-frame-interpolation-based-on-deformable-kernel-region_amd
 OUT=$PKG/lib_v$NAME
 mkdir -p $OUT
 STEM=${SRC%.hip}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed "$@" \
     -c $PKG/csrc/$SRC -o $OUT/$STEM.o
 OBJS=""
 for o in $PKG/lib/*.o; do

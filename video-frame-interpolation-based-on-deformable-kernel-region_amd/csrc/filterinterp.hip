@@ -387,26 +387,69 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_defor(
 // scattered to the clamped UNDISPLACED tap (the reference's own approximation) with atomics; filter
 // and offset-field gradients belong to this pixel alone (plain read-modify-write, the same values as
 // the reference's atomicAdd); flow gradient from the forward's quadrant sums.
-template <int VARIANT>
+// STAGED (round 3): the image-gradient addends of a 64x4 block are summed in a window of 64-bit LDS cells over the bounding
+// box of the block's clamped taps, three channels at a time, and leave with one global atomic per non-zero cell (exact
+// integer sums: the same bits as the per-tap scatter; see fi_backward_ori4_lds).  A block whose window does not fit, and
+// every block of a call with non-finite inputs, raises its flag and returns; the !STAGED instance, launched afterwards with
+// the flags, does those blocks only.
+#define FD_CH 3
+#define FD_CELLS 4608                               // 64-bit cells of LDS (36,864 bytes)
+// FS = 4: the filter size at compile time -- offsets, weights and the filter / offset gradient sums of the pixel live in
+// registers across the channel loop (summed in the same order from the cells' starting values: the same bits); FS = 0: any
+// filter size, the cells are read and written in global memory per channel and tap.
+template <int VARIANT, bool STAGED, int FS>
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     const float* __restrict__ in4, const float* __restrict__ gout, unsigned long long* __restrict__ acc,
-    const int* __restrict__ hdr, float* g1, float* g2, float* g3, float* g4,
-    int channel, int h, int w, int fs, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
+    const int* __restrict__ hdr, int* __restrict__ tileflag, float* g1, float* g2, float* g3, float* g4,
+    int channel, int h, int w, int fs_arg, vfi_strides s1, vfi_strides s2, vfi_strides s3, vfi_strides s4) {
+    const int fs = FS ? FS : fs_arg;
+    constexpr int NA = FS ? FS * FS : 1;
+    __shared__ unsigned long long cells[STAGED ? FD_CELLS : 1];
+    __shared__ int box[4];
     const int x = blockIdx.x * VFI_TX + threadIdx.x;
     const int y = blockIdx.y * VFI_TY + threadIdx.y;
-    if (x >= w || y >= h) return;
     const int b = blockIdx.z;
+    const int tile = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.y * VFI_TX + threadIdx.x;
+    if constexpr (!STAGED) {
+        if (tileflag && !tileflag[tile]) return;
+        if (x >= w || y >= h) return;
+    }
+    const bool inimg = x < w && y < h;
     const GradAccCtx gctx = gradacc_ctx(hdr);
-    const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
-    const float fx = flow[0];
-    const float fy = flow[s2.c];
+    float fx = 0.0f, fy = 0.0f;
+    if (inimg) {
+        const float* flow = in2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        fx = flow[0];
+        fy = flow[s2.c];
+    }
     const float x2 = (float)x + fx;
     const float y2 = (float)y + fy;
-    if (!fi_valid(fx, fy, x2, y2, w, h)) return;
+    const bool valid = inimg && fi_valid(fx, fy, x2, y2, w, h);
+    if constexpr (!STAGED) { if (!valid) return; }
     const int fs2 = fs * fs;
-    const int ix = (int)x2, iy = (int)y2;
+    const int ix = valid ? (int)x2 : 0, iy = valid ? (int)y2 : 0;
     const int L = ix + 1 - fs / 2, T = iy + 1 - fs / 2;
+    int bx0 = 0, by0 = 0, bw = 0, n = 0;
+    if constexpr (STAGED) {
+        if (tid == 0) { box[0] = INT_MAX; box[1] = INT_MAX; box[2] = INT_MIN; box[3] = INT_MIN; }
+        __syncthreads();
+        const int wx0 = wave_min_i32(valid ? clampi(L, 0, w - 1) : INT_MAX), wy0 = wave_min_i32(valid ? clampi(T, 0, h - 1) : INT_MAX);
+        const int wx1 = wave_max_i32(valid ? clampi(L + fs - 1, 0, w - 1) : INT_MIN), wy1 = wave_max_i32(valid ? clampi(T + fs - 1, 0, h - 1) : INT_MIN);
+        if ((tid & 63) == 0 && wx0 != INT_MAX) {
+            atomicMin(&box[0], wx0); atomicMin(&box[1], wy0);
+            atomicMax(&box[2], wx1); atomicMax(&box[3], wy1);
+        }
+        __syncthreads();
+        if (box[0] == INT_MAX) return;                      // (block-uniform: no pixel of the block has a gradient)
+        bx0 = box[0]; by0 = box[1]; bw = box[2] - box[0] + 1;
+        n = bw * (box[3] - box[1] + 1);
+        if (gctx.nonfinite || n * min(FD_CH, channel) > FD_CELLS) {      // (block-uniform) left to the !STAGED instance
+            if (tid == 0) tileflag[tile] = 1;
+            return;
+        }
+    }
     const float alpha = x2 - (float)ix;
     const float beta = y2 - (float)iy;
     const float* img = in1 + (int64_t)b * s1.b;
@@ -419,22 +462,47 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
     float* gopx = (VARIANT == VFI_DEFOR_NOFILTER) ? gfpx : g4 + (int64_t)b * s4.b + (int64_t)y * s4.h + x;
     const int64_t ocs = (VARIANT == VFI_DEFOR_NOFILTER) ? s3.c : s4.c;
     const float kq[4] = { (1.0f - alpha) * (1.0f - beta), alpha * (1.0f - beta), (1.0f - alpha) * beta, alpha * beta };
+    float offy[NA], offx[NA], wgts[NA], gfa[NA], goy[NA], gox[NA];
+    if constexpr (FS != 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            offy[k] = valid ? opx[(int64_t)k * ocs] : 0.0f;
+            offx[k] = valid ? opx[(int64_t)(fs2 + k) * ocs] : 0.0f;
+            goy[k] = valid ? gopx[(int64_t)k * ocs] : 0.0f;
+            gox[k] = valid ? gopx[(int64_t)(fs2 + k) * ocs] : 0.0f;
+            if constexpr (VARIANT != VFI_DEFOR_NOFILTER) {
+                wgts[k] = valid ? fpx[(int64_t)k * s3.c] : 0.0f;
+                gfa[k] = valid ? gfpx[(int64_t)k * s3.c] : 0.0f;
+            }
+        }
+    }
     float gx = 0.0f, gy = 0.0f;
-    for (int c = 0; c < channel; ++c) {
+    const int chunk = STAGED ? FD_CH : channel;
+    for (int c0 = 0; c0 < channel; c0 += chunk) {
+    const int cn = min(chunk, channel - c0);
+    if constexpr (STAGED) {
+        for (int e = tid; e < n * cn; e += VFI_TX * VFI_TY) cells[e] = 0ull;
+        __syncthreads();
+    }
+    for (int c = c0; c < c0 + cn && valid; ++c) {
         const float* p = img + (int64_t)c * s1.c;
         unsigned long long* gp = gimg + (int64_t)c * h * w;
+        unsigned long long* win = cells + (STAGED ? (c - c0) * n : 0);
         float* gfp = g1 + (int64_t)b * s1.b + (int64_t)c * s1.c;    // (the fp32 scatter of a call with non-finite inputs)
         const float g = gpx[(int64_t)c * s1.c];
         const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
                               g * (1.0f - alpha) * beta,          g * alpha * beta };
         float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
         for (int dj = 0; dj < fs; ++dj) {
             const int j = T + dj, cj = clampi(j, 0, h - 1);
+#pragma unroll
             for (int di = 0; di < fs; ++di) {
                 const int i = L + di, ci = clampi(i, 0, w - 1);
                 const int k = dj * fs + di;
-                const float fracY = (float)cj + opx[(int64_t)k * ocs];
-                const float fracX = (float)ci + opx[(int64_t)(fs2 + k) * ocs];
+                const int ka = FS ? k : 0;
+                const float fracY = (float)cj + (FS ? offy[ka] : opx[(int64_t)k * ocs]);
+                const float fracX = (float)ci + (FS ? offx[ka] : opx[(int64_t)(fs2 + k) * ocs]);
                 int quad;
                 if constexpr (VARIANT == VFI_DEFOR_OFFSET) quad = (j > iy ? 2 : 0) + (i > ix ? 1 : 0);
                 else if (fracX <= x2 && fracY <= y2) quad = 0;
@@ -461,17 +529,30 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
                 dX = fmaf(phiY, vBR, dX);
                 const int64_t o = (int64_t)cj * w + ci;
                 if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
-                    gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad], gctx);
+                    if constexpr (STAGED) atomicAdd(&win[(cj - by0) * bw + ci - bx0], (unsigned long long)__float2ll_rn(qg[quad] * gctx.scale));
+                    else gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad], gctx);
                     q[quad] = q[quad] + v;
-                    gopx[(int64_t)k * ocs] += g * kq[quad] * dY;
-                    gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX;
+                    if constexpr (FS != 0) {
+                        goy[ka] += g * kq[quad] * dY;
+                        gox[ka] += g * kq[quad] * dX;
+                    } else {
+                        gopx[(int64_t)k * ocs] += g * kq[quad] * dY;
+                        gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX;
+                    }
                 } else {
-                    const float wgt = fpx[(int64_t)k * s3.c];
-                    gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad] * wgt, gctx);
-                    gfpx[(int64_t)k * s3.c] += qg[quad] * v;
+                    const float wgt = FS ? wgts[ka] : fpx[(int64_t)k * s3.c];
+                    if constexpr (STAGED) atomicAdd(&win[(cj - by0) * bw + ci - bx0], (unsigned long long)__float2ll_rn(qg[quad] * wgt * gctx.scale));
+                    else gradacc_add(gp, gfp, o, (int64_t)cj * s1.h + ci, qg[quad] * wgt, gctx);
                     q[quad] = fmaf(v, wgt, q[quad]);
-                    gopx[(int64_t)k * ocs] += g * kq[quad] * dY * wgt;
-                    gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX * wgt;
+                    if constexpr (FS != 0) {
+                        gfa[ka] += qg[quad] * v;
+                        goy[ka] += g * kq[quad] * dY * wgt;
+                        gox[ka] += g * kq[quad] * dX * wgt;
+                    } else {
+                        gfpx[(int64_t)k * s3.c] += qg[quad] * v;
+                        gopx[(int64_t)k * ocs] += g * kq[quad] * dY * wgt;
+                        gopx[(int64_t)(fs2 + k) * ocs] += g * kq[quad] * dX * wgt;
+                    }
                 }
             }
         }
@@ -488,9 +569,32 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_defor(
             gy = fmaf(g, temp, gy);
         }
     }
-    float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
-    gf[0] = gx;
-    gf[s2.c] = gy;
+    if constexpr (STAGED) {
+        __syncthreads();
+        for (int e = tid; e < n * cn; e += VFI_TX * VFI_TY) {
+            const unsigned long long v = cells[e];
+            if (v != 0ull) {
+                const int cc = e / n, r = e - cc * n;
+                const int cy = r / bw, cx = r - cy * bw;
+                atomicAdd(&gimg[(int64_t)(c0 + cc) * h * w + (int64_t)(by0 + cy) * w + bx0 + cx], v);
+            }
+        }
+        __syncthreads();                                    // (the next pass zeroes the cells)
+    }
+    }
+    if (valid) {
+        float* gf = g2 + (int64_t)b * s2.b + (int64_t)y * s2.h + x;
+        gf[0] = gx;
+        gf[s2.c] = gy;
+        if constexpr (FS != 0) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                gopx[(int64_t)k * ocs] = goy[k];
+                gopx[(int64_t)(fs2 + k) * ocs] = gox[k];
+                if constexpr (VARIANT != VFI_DEFOR_NOFILTER) gfpx[(int64_t)k * s3.c] = gfa[k];
+            }
+        }
+    }
 }
 
 }  // namespace vfi
@@ -652,26 +756,24 @@ extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1,
     unsigned long long* acc;
     int* hdr;
     // (the tap weights of the variant without a filter are 1)
+    int* flags = nullptr;                                   // one word per block: "the staged instance left it alone"
     const int err = gradacc_begin(st, gradoutput, batch, channel, h, w, s1, variant == VFI_DEFOR_NOFILTER ? nullptr : input3,
-                                  filter_size * filter_size, s3, &acc, &hdr);
+                                  filter_size * filter_size, s3, &acc, &hdr, (int)(grid.x * grid.y * grid.z), &flags);
     if (err != VFI_OK) return err;
+#define FD_LAUNCH2(V, F, I3, I4, G3, G4, S4) \
+        hipLaunchKernelGGL((fi_backward_defor<V, true, F>), grid, block, 0, st, input1, input2, I3, I4, gradoutput, acc, hdr, flags, \
+                           gradinput1, gradinput2, G3, G4, channel, h, w, filter_size, s1, s2, s3, S4); \
+        hipLaunchKernelGGL((fi_backward_defor<V, false, F>), grid, block, 0, st, input1, input2, I3, I4, gradoutput, acc, hdr, flags, \
+                           gradinput1, gradinput2, G3, G4, channel, h, w, filter_size, s1, s2, s3, S4)
+#define FD_LAUNCH(V, I3, I4, G3, G4, S4) \
+        if (filter_size == 4) { FD_LAUNCH2(V, 4, I3, I4, G3, G4, S4); } else { FD_LAUNCH2(V, 0, I3, I4, G3, G4, S4); }
     switch (variant) {
-    case VFI_DEFOR_OFFSET:
-        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_OFFSET>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
-                           s1, s2, s3, s4);
-        break;
-    case VFI_DEFOR_REGION:
-        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_REGION>, grid, block, 0, st, input1, input2, input3, input4,
-                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput4, channel, h, w, filter_size,
-                           s1, s2, s3, s4);
-        break;
-    default:
-        hipLaunchKernelGGL(fi_backward_defor<VFI_DEFOR_NOFILTER>, grid, block, 0, st, input1, input2, input3, input3,
-                           gradoutput, acc, hdr, gradinput1, gradinput2, gradinput3, gradinput3, channel, h, w, filter_size,
-                           s1, s2, s3, s3);
-        break;
+    case VFI_DEFOR_OFFSET: FD_LAUNCH(VFI_DEFOR_OFFSET, input3, input4, gradinput3, gradinput4, s4); break;
+    case VFI_DEFOR_REGION: FD_LAUNCH(VFI_DEFOR_REGION, input3, input4, gradinput3, gradinput4, s4); break;
+    default:               FD_LAUNCH(VFI_DEFOR_NOFILTER, input3, input3, gradinput3, gradinput3, s3); break;
     }
+#undef FD_LAUNCH
+#undef FD_LAUNCH2
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return gradacc_finish(st, acc, hdr, gradinput1, batch, channel, h, w, s1);
 }
