@@ -17,11 +17,28 @@ __device__ __forceinline__ float fi4_pixel(const float (&v)[16], const float (&f
     return blend4(alpha, beta, TL, TR, BL, BR);
 }
 
-// Row of staged element e in a window whose row pitch is a multiple of 32 elements (e < 2^15): floor(e / pitch) through a
-// float reciprocal of the small integer pitch / 32 -- (q + 0.5) / m never comes within 0.5 / m of an integer, far more than
-// the reciprocal's error -- instead of a 32-bit integer division (~40 instructions, once per staged element and tile).
-__device__ __forceinline__ int fi_row_of(int e, float inv_pitch32) {
-    return (int)(((float)(e >> 5) + 0.5f) * inv_pitch32);
+// Row of staged element e (e < 2^15) in a window of row pitch p: floor(e / p) through a float reciprocal -- (e + 0.5) / p never
+// comes within 0.5 / p of an integer, while the two roundings are off by less than 2e-3 / p (the quotient is at most 2^15 / p)
+// -- instead of a 32-bit integer division (~40 instructions, once per staged element and tile).
+__device__ __forceinline__ int fi_row_of(int e, float inv_pitch) {
+    return (int)(((float)e + 0.5f) * inv_pitch);
+}
+
+// LDS row pitch of a staged window bw elements (dwords) wide: a multiple of the 32 banks, plus FI_PITCH_SKEW.
+// The LDS serves the 4-byte tap reads 32 lanes per clock on 32 banks (measured with rocprofv3's SQ_LDS_BANK_CONFLICT on
+// controlled flow fields, tools/lds_conflicts.sh).  fp32 windows: 32 neighbouring lanes read 32 different columns, so with a
+// pitch that is a multiple of 32 a tap's bank depends on its column only and lanes that sit on different window rows (a step
+// in the flow's vertical part) cannot collide -- 0 conflict cycles on such fields, 50 % with a skew of 8 or 16; what is left
+// on a smooth field are the lanes a stretching flow pushes onto a 33rd column.  fp16 windows: two neighbouring lanes share
+// a dword -- a broadcast while they sit on one row, a two-way conflict when the step falls between them (50 % conflict
+// cycles on a field with a step per 20 lanes, 45 % on the smooth field).  There the 32 lanes use 16-17 banks, and a skew of
+// 16 dwords puts the next row's copy of a dword on a bank none of them uses: conflict cycles on the smooth field 138 M ->
+// 63 M per C=196 launch (-4.5 % time), on the quarter field 637 M -> 412 M (-20 %).
+#ifndef FI_PITCH_SKEW
+#define FI_PITCH_SKEW 0
+#endif
+__device__ __forceinline__ int fi_pitch_for(int bw) {
+    return FI_PITCH_SKEW ? (((max(bw - FI_PITCH_SKEW, 0) + 31) & ~31) + FI_PITCH_SKEW) : ((bw + 31) & ~31);
 }
 
 // channel loop of one valid pixel gathering straight from global memory.  Row by row, so the

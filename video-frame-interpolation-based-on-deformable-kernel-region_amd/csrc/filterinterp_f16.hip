@@ -20,6 +20,7 @@
 //   * image columns are never replicated in LDS (a dword holds two pixels, so per-pixel clamping
 //     of a dword load is impossible): a pixel whose taps leave the image left or right gets its
 //     window moved inside and the weights of the clamped taps added onto the column they clamp to.
+#define FI_PITCH_SKEW 16                            // (dwords; see fi_pitch_for)
 #include "filterinterp_dev.h"
 
 #include <hip/hip_fp16.h>
@@ -136,7 +137,7 @@ __device__ __forceinline__ void f16_run_channels(const __half* __restrict__ img,
     // dword e = tid + k*F16_THREADS of the staged window, row-major, `pitch` dwords per row; rows
     // clamped to the image, columns never out of it; pad dwords get an out-of-range offset (the
     // load returns 0 without touching memory)
-    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
+    const float inv_pitch32 = 1.0f / (float)win.pitch;
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(F16_THREADS, 4) void fi_forward_ori_lds_f16(
     const int bx0 = any_valid ? box[0] & ~1 : 0, by0 = box[1];          // even: dword-aligned rows
     const int bw = any_valid ? (box[2] - bx0 + 2) >> 1 : 0;              // dwords per row
     const int bh = any_valid ? box[3] - by0 + 1 : 0;
-    const int pitch = (bw + 31) & ~31;                                    // a multiple of the 32 banks
+    const int pitch = fi_pitch_for(bw);
     const int n = pitch * bh;
 
     // ---- folded tap weights: filter tap x bilinear quadrant weight, clamped columns merged

@@ -123,7 +123,7 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
     // channel from scalars) + one 32-bit byte offset per element that never changes -- no
     // per-channel vector address arithmetic, one VGPR per element.  One buffer_load_dword ... lds
     // writes 64 consecutive floats: LDS destination = wave-uniform base + lane*4 = this layout.
-    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
+    const float inv_pitch32 = 1.0f / (float)win.pitch;
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -233,7 +233,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     constexpr int D = R - 1;
     static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
     if (c_begin >= c_end) return;
-    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
+    const float inv_pitch32 = 1.0f / (float)win.pitch;
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(FI_THREADS, 8 / FI_PX) void fi_forward_ori_lds(
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
     const int bh = raw_bh;
     // LDS row pitch: a multiple of the 32 banks; 8-byte reads see 64 banks: = 32 mod 64
-    const int pitch = use64 ? (((bw + 31) >> 6) << 6) + 32 : (bw + 31) & ~31;
+    const int pitch = use64 ? (((bw + 31) >> 6) << 6) + 32 : fi_pitch_for(bw);
     const int n = pitch * bh;                               // <= (w+33)*(h+2): fits int for any real frame
 
 #pragma unroll

@@ -84,7 +84,7 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
     if (c_begin >= c_end) return;
     // staged element e = tid + k * FM_THREADS, row pitch a multiple of the 32 LDS banks, borders replicated while
     // staging, pad elements out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
-    const float inv_pitch32 = 1.0f / (float)(win.pitch >> 5);          // (the pitch is a multiple of 32)
+    const float inv_pitch32 = 1.0f / (float)win.pitch;
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
