@@ -295,7 +295,7 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     if half:
         kernel = kernel.replace("fi_forward_ori_lds", "fi_forward_ori_lds_f16").replace("direct<true>", "direct_f16")
     roofline = roofline_block(kernel, px, fi196_ms, len(fi196_events),
-                              None if half else traffic_lookup(h, w, args.flow_model, args.direct), 856.0 if half else 1640.0)
+                              traffic_lookup(h, w, args.flow_model, args.direct, "fi196_f16" if half else "fi196"), 856.0 if half else 1640.0)
 
     out = {
         "metric": "interpolated frames/sec at 1080p (hot path only: correlation + DepthFlowProjection + "
@@ -333,7 +333,8 @@ def roofline_block(kernel, px, ms, launches, traffic, bytes_per_px=1640.0):
 
 
 def traffic_lookup(h, w, flow_model, direct, op="fi196"):
-    """HBM bytes per call of `op` (fi196: the C=196 launch; fi_c3; flowproj: all three launches of a call) from the
+    """HBM bytes per call of `op` (fi196: the C=196 launch; fi196_f16: the same with fp16 storage; fi_c3; flowproj: all three
+    launches of a call) from the
     committed rocprofv3 PMC passes -- only for the exact (frame size, flow model, kernel) they were collected on
     (profiles/README.md says how); anything else has no counter evidence: null."""
     path = os.path.join(ROOT, "profiles", "traffic_by_config.json")
@@ -441,6 +442,7 @@ def fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank):
     gbs = 856.0 * wl.px / ms / 1e6
     return {"kernel": "fi_forward_ori_lds_f16 (C=196, image and output fp16, flow / filter / arithmetic fp32)",
             "avg_launch_ms": round(ms, 4), "algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic_lookup(h, w, args.flow_model, False, "fi196_f16"), "algorithmic_bytes_per_launch": 856.0 * wl.px,
             "steps_timed": steps, "ms_per_step": round(step_ms, 4), "frames_per_s": round(len(TIMES) / (step_ms * 1e-3), 1),
             "step": "measured: 10 half correlations + 6 DepthFlowProjection (fp32) + 6 + 6 half-storage FilterInterpolation"}
 

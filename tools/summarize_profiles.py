@@ -121,6 +121,21 @@ if gate["flowproj"]:
                     "kernel": "vfi::proj_scan4<false> + proj_pull_lean<false> + proj_finish (one FlowProjection call)",
                     "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": 20.0 * PX,
                     "ratio": round((rd + wr) / (20.0 * PX), 3), "source": "profiles/%s_gate_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE, summed over the three launches)" % tag})
+# (round 3) the fp16-storage C=196 launch and the finest correlation level: tools/collect_extras.sh
+extras = os.path.join(os.path.dirname(src), "extras_" + tag)
+if os.path.exists(os.path.join(extras, "f16_corr_pmc.json")):
+    shutil.copy(os.path.join(extras, "f16_corr_pmc.json"), os.path.join(dst, tag + "_f16_corr_pmc.json"))
+    shutil.copy(os.path.join(extras, "rest_ops.txt"), os.path.join(dst, tag + "_rest_ops.txt"))
+    with open(os.path.join(extras, "f16_corr_pmc.json")) as fh:
+        ex = json.load(fh)
+    for op, block, kern, alg in (("fi196_f16", ex.get("f16", {}), "fi_forward_ori_lds_f16", 856.0 * PX),
+                                 ("corr_finest", ex.get("corr", {}), "corr_forward_k1_rows2", (2 * 32 + 81) * 4.0 * (H // 4) * (W // 4))):
+        for k, v in block.items():
+            if kern in k:
+                rd, wr = v["read_bytes (EA_RDREQ x 128 B)"], v["write_bytes (WRITE_SIZE x 1024)"]
+                entries.append({"h": H, "w": W, "flow_model": "smooth", "direct": False, "op": op, "kernel": k,
+                                "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": alg,
+                                "ratio": round((rd + wr) / alg, 3), "source": "profiles/%s_f16_corr_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
 with open(os.path.join(dst, "traffic_by_config.json"), "w") as fh:
     json.dump({"entries": entries}, fh, indent=1)
 print(json.dumps(entries, indent=1))
