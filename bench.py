@@ -71,6 +71,10 @@ def parse(argv=None):
                     help="slowmo1080: f16 = BASELINE.json configs[2], frames / context / correlation features and their "
                          "outputs stored as fp16, flows, filters, depth and all arithmetic fp32")
     ap.add_argument("--vimeo-batch", type=int, default=3, help="vimeo64: triplets per call (the reference's PWC-Net allows 3)")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="slowmo1080: 2 = the step's launches on two HIP streams, ordered by the network's data dependencies "
+                         "(correlation chains of the two directions side by side; later projections and the frame warps under "
+                         "the context warps); 1 = one stream, the reference's call order")
     ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
@@ -280,9 +284,53 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
             for d in range(2):
                 fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img)
 
+    # The same 46 launches on two streams, ordered by what the network's data flow allows (DAIN_slowmotion.py:147-183): the
+    # flow of direction d needs only direction d's correlations, FlowProject(d, t) only flow d, and the warps of time offset t
+    # only the projections of t.  Main stream: correlations of direction 0, the first projection, then the six context
+    # warps as their projections arrive.  Side stream: correlations of direction 1, the other five projections, then the
+    # six frame warps.  The library keeps one projection workspace per stream; each stream has its own count plane.
+    side = torch.cuda.Stream(dev)
+    count2 = torch.empty_like(wl.count)
+
+    def step2(i, record=False):
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                              # the previous step's readers of projs / outputs are done
+        done = {}
+        with torch.cuda.stream(side):
+            for a, b in wl.corr[1]:
+                cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+        for a, b in wl.corr[0]:
+            cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+        assert cabi.depthflowprojection_forward(wl.flows[0][0], wl.depth[0], wl.count, wl.projs[0][0], 1) == 0
+        done[(0, 0)] = main.record_event()
+        with torch.cuda.stream(side):
+            for ti in range(len(TIMES)):
+                for d in range(2):
+                    if (d, ti) == (0, 0):
+                        continue
+                    assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], count2, wl.projs[d][ti], 1) == 0
+                    done[(d, ti)] = side.record_event()
+            side.wait_event(done[(0, 0)])
+            for ti in range(len(TIMES)):
+                for d in range(2):
+                    fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img)
+        for ti in range(len(TIMES)):
+            for d in range(2):
+                if (d, ti) != (0, 0):
+                    main.wait_event(done[(d, ti)])
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                fi(wl.ctx[d], wl.projs[d][ti], wl.filters[d], wl.out_ctx)
+                if record:
+                    e1.record()
+                    fi196_events.append((e0, e1))
+        main.wait_stream(side)                              # the step ends when both streams have
+
+    run_step = step2 if args.streams == 2 else step
     for i in range(args.warmup):
-        step(i)
-    elapsed = runner.timed_region(lambda i: step(i, record=True), args.steps, dev)
+        run_step(i)
+    elapsed = runner.timed_region(lambda i: run_step(i, record=True), args.steps, dev)
     frames_total = runner.total_units(len(TIMES) * args.steps)
     value = frames_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -308,6 +356,9 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
                                "6 FilterInterpolation(C=196) + 6 FilterInterpolation(C=3); 3 frames/step"
                                % (args.height, args.width, h, w),
                    "flow_model": args.flow_model, "filter_size": 4, "batch": 1, "storage": args.storage,
+                   "streams": args.streams,
+                   "schedule": ("two HIP streams, launches ordered by the network's data dependencies" if args.streams == 2
+                                else "one stream, the reference's call order"),
                    "parallelism": "replicas x%d (one pair per GPU, no collective)" % world},
         "roofline": roofline,
     }
@@ -319,6 +370,18 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
         out["gate"] = gate_measurement(torch, cabi, S, wl, dev, args)
         out["fp16_storage"] = fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank)
         out["shared_window"] = shared_window_measurement(torch, cabi, wl, dev, args)
+        if args.streams == 1:
+            # the same launches on two streams (`--streams 2` makes this the timed region): reported beside the headline,
+            # whose step keeps one stream and the reference's call order
+            n2 = max(5, args.steps // 2)
+            for i in range(2):
+                step2(i)
+            el2 = runner.timed_region(lambda i: step2(i), n2, dev)
+            out["two_streams"] = {"schedule": "correlation chains of the two directions side by side; projections 2-6 and the six "
+                                              "frame warps on a side stream under the context warps (data dependencies of "
+                                              "networks/DAIN_slowmotion.py:147-183 kept)",
+                                  "steps_timed": n2, "ms_per_step": round(el2 / n2 * 1e3, 4),
+                                  "frames_per_s": round(len(TIMES) * n2 / el2, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(torch, cabi, wl, dev, args)
     return out
