@@ -308,6 +308,47 @@ def test_deformable_backward_staged_and_flagged_blocks(torch_mod, cabi, oracle, 
         assert np.array_equal(cpu(gf), r3)
 
 
+def test_two_streams_same_bits_as_one(torch_mod, cabi):
+    """`bench.py --streams 2` / INTEGRATION.md: projections on two streams at once (each stream has its own workspace and
+    count plane), their consumers ordered by events on the other stream.  Same bits as the same calls on one stream,
+    repeated so that the streams really overlap."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    H, W, C = 192, 320, 8
+    flows = [gpu(torch, smooth_flow(rng, 1, H, W, 6.0)) for _ in range(4)]
+    depth = gpu(torch, (1e-6 + np.exp(-rng.normal(size=(1, 1, H, W)))).astype(f32))
+    ctx = gpu(torch, rng.random((1, C, H, W), dtype=f32))
+    filt = gpu(torch, rng.random((1, 16, H, W), dtype=f32))
+
+    def run(two):
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev) if two else main
+        projs = [torch.zeros((1, 2, H, W), device=dev) for _ in flows]
+        outs = [torch.empty_like(ctx) for _ in flows]
+        counts = [torch.zeros((1, 1, H, W), device=dev) for _ in range(2)]
+        side.wait_stream(main)
+        done = []
+        for k, fl in enumerate(flows):
+            st = side if (k % 2) else main
+            with torch.cuda.stream(st):
+                assert cabi.depthflowprojection_forward(fl, depth, counts[k % 2], projs[k], 1) == 0
+                done.append(st.record_event())
+        for k in range(len(flows)):                          # every warp on the stream that did NOT project its flow
+            st = main if (k % 2) else side
+            with torch.cuda.stream(st):
+                st.wait_event(done[k])
+                assert cabi.filterinterp_forward_ori(ctx, projs[k], filt, outs[k]) == 0
+        main.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        return [cpu(t) for t in projs + outs]
+
+    ref = run(False)
+    for _ in range(5):
+        got = run(True)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+
+
 # ------------------------------------------------------------------ fp16 storage (BASELINE configs[2], SURVEY 8d)
 
 def gpu16(torch, a):
