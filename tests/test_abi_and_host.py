@@ -317,3 +317,17 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
             assert not spills, "%s %s: %d scratch operations inside an LDS-DMA pipeline: %s" % (
                 name, b["label"], len(spills), spills[:3])
     assert checked >= 60                    # every K instantiation of every staged kernel was looked at
+
+
+def test_row_of_staged_element_division_is_exact():
+    """csrc/filterinterp_dev.h: fi_row_of() finds the window row of a staged element as (int)((e + 0.5f) * (1.0f / pitch)) --
+    the staged kernels' LDS layout and DMA addresses depend on it being floor(e / pitch) for every pitch they can choose
+    (any positive value since the fp16 kernel's pitch is 32k + 16) and every element index below 2^15.  Checked
+    exhaustively in IEEE float32, also with a reciprocal that is one ulp off in either direction."""
+    import numpy as np
+    e = np.arange(0, 1 << 15, dtype=np.int32)
+    ef = e.astype(np.float32) + np.float32(0.5)
+    for pitch in range(1, 8193):
+        exact = np.float32(1.0) / np.float32(pitch)
+        for inv in (exact, np.nextafter(exact, np.float32(0.0)), np.nextafter(exact, np.float32(2.0))):
+            assert np.array_equal((ef * inv).astype(np.int32), e // pitch), pitch
