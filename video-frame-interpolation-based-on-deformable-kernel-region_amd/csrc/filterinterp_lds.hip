@@ -50,7 +50,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #define FI_TW 64
+#ifndef FI_TH
 #define FI_TH 16
+#endif
 #ifndef FI_PX
 #define FI_PX 2                                     // pixels per thread (rows y, y + FI_TH/FI_PX, ...)
 #endif
@@ -58,7 +60,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_PASS_ROWS (FI_TH / FI_PX)
 #define FI_KS (FI_PX / 2)                           // staged elements per thread scale with the pixels per thread
 #define FI_HDR 16                                   // floats at the head of the LDS array (bounding box)
+#ifndef FI_RING_FLOATS
 #define FI_RING_FLOATS 15984                        // LDS ring: 16000 floats = 64,000 B with the header
+#endif
 #ifndef FI_RMAX
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
 #endif
