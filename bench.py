@@ -72,9 +72,8 @@ def parse(argv=None):
                          "outputs stored as fp16, flows, filters, depth and all arithmetic fp32")
     ap.add_argument("--vimeo-batch", type=int, default=3, help="vimeo64: triplets per call (the reference's PWC-Net allows 3)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
-                    help="slowmo1080: 2 = the step's launches on two HIP streams, ordered by the network's data dependencies "
-                         "(correlation chains of the two directions side by side; later projections and the frame warps under "
-                         "the context warps); 1 = one stream, the reference's call order")
+                    help="slowmo1080: 2 = one HIP stream per flow direction (the two directions are independent chains of "
+                         "correlations, projections and warps); 1 = one stream, the reference's call order")
     ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
@@ -284,47 +283,34 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
             for d in range(2):
                 fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img)
 
-    # The same 46 launches on two streams, ordered by what the network's data flow allows (DAIN_slowmotion.py:147-183): the
-    # flow of direction d needs only direction d's correlations, FlowProject(d, t) only flow d, and the warps of time offset t
-    # only the projections of t.  Main stream: correlations of direction 0, the first projection, then the six context
-    # warps as their projections arrive.  Side stream: correlations of direction 1, the other five projections, then the
-    # six frame warps.  The library keeps one projection workspace per stream; each stream has its own count plane.
+    # The same 46 launches on two streams, one per flow direction: direction d's chain -- its correlations, FlowProject(d, t),
+    # FilterInterpolate_ctx / FilterInterpolate on ctx d / frame d -- needs nothing of the other direction's
+    # (networks/DAIN_slowmotion.py:147-183: the two directions meet only in the blend and the rectify network, after the
+    # hot path).  No cross-stream event inside the step; the library keeps one projection workspace per stream, and each
+    # stream has its own count plane and output tensors.  The two 196-channel launches that run side by side fill each
+    # other's tails (a launch ends with 40 of its 6,696 workgroups running alone).
     side = torch.cuda.Stream(dev)
-    count2 = torch.empty_like(wl.count)
+    count2, out_ctx2, out_img2 = torch.empty_like(wl.count), torch.empty_like(wl.out_ctx), torch.empty_like(wl.out_img)
 
     def step2(i, record=False):
         main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)                              # the previous step's readers of projs / outputs are done
-        done = {}
-        with torch.cuda.stream(side):
-            for a, b in wl.corr[1]:
-                cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
-        for a, b in wl.corr[0]:
-            cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
-        assert cabi.depthflowprojection_forward(wl.flows[0][0], wl.depth[0], wl.count, wl.projs[0][0], 1) == 0
-        done[(0, 0)] = main.record_event()
-        with torch.cuda.stream(side):
-            for ti in range(len(TIMES)):
-                for d in range(2):
-                    if (d, ti) == (0, 0):
-                        continue
-                    assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], count2, wl.projs[d][ti], 1) == 0
-                    done[(d, ti)] = side.record_event()
-            side.wait_event(done[(0, 0)])
-            for ti in range(len(TIMES)):
-                for d in range(2):
-                    fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], wl.out_img)
-        for ti in range(len(TIMES)):
-            for d in range(2):
-                if (d, ti) != (0, 0):
-                    main.wait_event(done[(d, ti)])
-                if record:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                fi(wl.ctx[d], wl.projs[d][ti], wl.filters[d], wl.out_ctx)
-                if record:
-                    e1.record()
-                    fi196_events.append((e0, e1))
+        side.wait_stream(main)                              # the previous step's work is done
+        for d, st, cnt, oc, oi in ((0, main, wl.count, wl.out_ctx, wl.out_img), (1, side, count2, out_ctx2, out_img2)):
+            with torch.cuda.stream(st):
+                for a, b in wl.corr[d]:
+                    cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+                for ti in range(len(TIMES)):
+                    err = cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], cnt, wl.projs[d][ti], 1)
+                    assert err == 0, err
+                for ti in range(len(TIMES)):
+                    if record and d == 0:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    fi(wl.ctx[d], wl.projs[d][ti], wl.filters[d], oc)
+                    if record and d == 0:
+                        e1.record()
+                        fi196_events.append((e0, e1))
+                    fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], oi)
         main.wait_stream(side)                              # the step ends when both streams have
 
     run_step = step2 if args.streams == 2 else step
@@ -357,7 +343,8 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
                                % (args.height, args.width, h, w),
                    "flow_model": args.flow_model, "filter_size": 4, "batch": 1, "storage": args.storage,
                    "streams": args.streams,
-                   "schedule": ("two HIP streams, launches ordered by the network's data dependencies" if args.streams == 2
+                   "schedule": ("one HIP stream per flow direction (two 196-channel launches run side by side: roofline.avg_launch_ms "
+                                "is the duration of one of them while it shares the GPU)" if args.streams == 2
                                 else "one stream, the reference's call order"),
                    "parallelism": "replicas x%d (one pair per GPU, no collective)" % world},
         "roofline": roofline,
@@ -377,9 +364,8 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
             for i in range(2):
                 step2(i)
             el2 = runner.timed_region(lambda i: step2(i), n2, dev)
-            out["two_streams"] = {"schedule": "correlation chains of the two directions side by side; projections 2-6 and the six "
-                                              "frame warps on a side stream under the context warps (data dependencies of "
-                                              "networks/DAIN_slowmotion.py:147-183 kept)",
+            out["two_streams"] = {"schedule": "one HIP stream per flow direction: its correlations, projections and warps (the "
+                                              "directions are independent chains, networks/DAIN_slowmotion.py:147-183)",
                                   "steps_timed": n2, "ms_per_step": round(el2 / n2 * 1e3, 4),
                                   "frames_per_s": round(len(TIMES) * n2 / el2, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
