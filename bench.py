@@ -289,14 +289,14 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     # hot path).  No cross-stream event inside the step; the library keeps one projection workspace per stream, and each
     # stream has its own count plane and output tensors.  The two 196-channel launches that run side by side fill each
     # other's tails (a launch ends with 40 of its 6,696 workgroups running alone).
-    side = torch.cuda.Stream(dev)
+    from vfidkr_amd import fused
+    lanes = fused.DirectionStreams(dev)
     count2, out_ctx2, out_img2 = torch.empty_like(wl.count), torch.empty_like(wl.out_ctx), torch.empty_like(wl.out_img)
 
     def step2(i, record=False):
-        main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)                              # the previous step's work is done
-        for d, st, cnt, oc, oi in ((0, main, wl.count, wl.out_ctx, wl.out_img), (1, side, count2, out_ctx2, out_img2)):
-            with torch.cuda.stream(st):
+        # (direction 1 first: its stream forks from what the current stream holds BEFORE this step's direction-0 launches)
+        for d, cnt, oc, oi in ((1, count2, out_ctx2, out_img2), (0, wl.count, wl.out_ctx, wl.out_img)):
+            with lanes.direction(d):
                 for a, b in wl.corr[d]:
                     cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
                 for ti in range(len(TIMES)):
@@ -311,7 +311,7 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
                         e1.record()
                         fi196_events.append((e0, e1))
                     fi(wl.frames[d], wl.projs[d][ti], wl.filters[d], oi)
-        main.wait_stream(side)                              # the step ends when both streams have
+        lanes.join()                                        # the step ends when both streams have
 
     run_step = step2 if args.streams == 2 else step
     for i in range(args.warmup):

@@ -349,6 +349,44 @@ def test_two_streams_same_bits_as_one(torch_mod, cabi):
         assert all(np.array_equal(a, b) for a, b in zip(ref, got))
 
 
+def test_direction_streams_helper(torch_mod, cabi):
+    """fused.DirectionStreams: one stream per flow direction (projection, then two warps that read it), joined at the end;
+    the same bits as the calls in a row, over several repetitions."""
+    torch = torch_mod
+    from vfidkr_amd import fused
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(78)
+    H, W, C = 160, 256, 12
+    flows = [gpu(torch, smooth_flow(rng, 1, H, W, 5.0)) for _ in range(2)]
+    depth = [gpu(torch, (1e-6 + np.exp(-rng.normal(size=(1, 1, H, W)))).astype(f32)) for _ in range(2)]
+    ctx = [gpu(torch, rng.random((1, C, H, W), dtype=f32)) for _ in range(2)]
+    frame = [gpu(torch, rng.random((1, 3, H, W), dtype=f32)) for _ in range(2)]
+    filt = [gpu(torch, rng.random((1, 16, H, W), dtype=f32)) for _ in range(2)]
+
+    def chain(d, res):
+        count, proj = torch.zeros((1, 1, H, W), device=dev), torch.zeros((1, 2, H, W), device=dev)
+        oc, oi = torch.empty_like(ctx[d]), torch.empty_like(frame[d])
+        assert cabi.depthflowprojection_forward(flows[d], depth[d], count, proj, 1) == 0
+        assert cabi.filterinterp_forward_ori(ctx[d], proj, filt[d], oc) == 0
+        assert cabi.filterinterp_forward_ori(frame[d], proj, filt[d], oi) == 0
+        res[d] = (proj, oc, oi)
+
+    ref = {}
+    for d in (0, 1):
+        chain(d, ref)
+    torch.cuda.synchronize(dev)
+    lanes = fused.DirectionStreams(dev)
+    for _ in range(5):
+        got = {}
+        for d in (1, 0):
+            with lanes.direction(d):
+                chain(d, got)
+        lanes.join()
+        torch.cuda.synchronize(dev)
+        for d in (0, 1):
+            assert all(torch.equal(a, b) for a, b in zip(ref[d], got[d]))
+
+
 # ------------------------------------------------------------------ fp16 storage (BASELINE configs[2], SURVEY 8d)
 
 def gpu16(torch, a):
