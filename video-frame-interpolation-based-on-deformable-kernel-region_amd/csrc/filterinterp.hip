@@ -741,6 +741,13 @@ extern "C" int vfi_filterinterp_forward_defor_general(int variant, const float* 
                          s4, stream);
 }
 
+// defined in filterinterp_defor_bwd_lds.hip
+extern "C" int vfi_filterinterp_backward_defor_lds(int variant, const float* input1, const float* input2, const float* input3,
+                                                    const float* input4, const float* gradoutput, unsigned long long* acc,
+                                                    const int* hdr, int* flags, float* gradinput2, float* gradinput3,
+                                                    float* gradinput4, int batch, int channel, int h, int w, vfi_strides s1,
+                                                    vfi_strides s2, vfi_strides s3, vfi_strides s4, vfi_stream_t stream);
+
 extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1, const float* input2,
                                                 const float* input3, const float* input4, const float* gradoutput,
                                                 float* gradinput1, float* gradinput2, float* gradinput3,
@@ -765,8 +772,17 @@ extern "C" int vfi_filterinterp_backward_defor(int variant, const float* input1,
                            gradinput1, gradinput2, G3, G4, channel, h, w, filter_size, s1, s2, s3, S4); \
         hipLaunchKernelGGL((fi_backward_defor<V, false, F>), grid, block, 0, st, input1, input2, I3, I4, gradoutput, acc, hdr, flags, \
                            gradinput1, gradinput2, G3, G4, channel, h, w, filter_size, s1, s2, s3, S4)
+    // fs == 4: the LDS-staged kernel (filterinterp_defor_bwd_lds.hip), then the per-tap instance for the blocks it flagged
 #define FD_LAUNCH(V, I3, I4, G3, G4, S4) \
-        if (filter_size == 4) { FD_LAUNCH2(V, 4, I3, I4, G3, G4, S4); } else { FD_LAUNCH2(V, 0, I3, I4, G3, G4, S4); }
+        if (staged4 == 0) hipLaunchKernelGGL((fi_backward_defor<V, false, 4>), grid, block, 0, st, input1, input2, I3, I4, gradoutput, acc, hdr, flags, \
+                                             gradinput1, gradinput2, G3, G4, channel, h, w, filter_size, s1, s2, s3, S4); \
+        else { FD_LAUNCH2(V, 0, I3, I4, G3, G4, S4); }
+    int staged4 = -1;
+    if (filter_size == 4) {
+        staged4 = vfi_filterinterp_backward_defor_lds(variant, input1, input2, input3, input4, gradoutput, acc, hdr, flags, gradinput2,
+                                                      gradinput3, gradinput4, batch, channel, h, w, s1, s2, s3, s4, stream);
+        if (staged4 != 0 && staged4 != -1) return VFI_ERR_LAUNCH;
+    }
     switch (variant) {
     case VFI_DEFOR_OFFSET: FD_LAUNCH(VFI_DEFOR_OFFSET, input3, input4, gradinput3, gradinput4, s4); break;
     case VFI_DEFOR_REGION: FD_LAUNCH(VFI_DEFOR_REGION, input3, input4, gradinput3, gradinput4, s4); break;
