@@ -190,69 +190,84 @@ __global__ __launch_bounds__(DB_THREADS, 2) void fi_backward_defor_lds(
         __syncthreads();
 
         if (valid) {
-#pragma unroll 1
-            for (int cc = 0; cc < cn; ++cc) {
-                const float g = cc == 0 ? gv[0] : cc == 1 ? gv[1] : gv[2];
-                const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
-                                      g * (1.0f - alpha) * beta,          g * alpha * beta };
-                const float* base = wins + cc * DB_WIN_FLOATS;
-                unsigned long long* win = cells + cc * ncell;
-                float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            // taps outside, the pass's channels inside: a tap's corner index, fractions, products of fractions and quadrant
+            // masks are formed once for the three channels.  Every sum keeps its order: a tap's filter / offset gradient
+            // sums visit the channels in increasing order, a channel's quadrant sums the taps in increasing order.
+            float qg[DB_CH][4], q[DB_CH][4];
 #pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    const int dj = k / FS, di = k % FS;
-                    int o = lb[k];
-                    float phiY = phy[k], phiX = phx[k];
-                    asm volatile("" : "+v"(o), "+v"(phiY), "+v"(phiX));    // (corner weights and second-row addresses re-derived per channel: registers)
-                    const float* t = base + o;
-                    const float vTL = t[0], vTR = t[1], vBL = t[pitch], vBR = t[pitch + 1];
-                    float v = ((1.0f - phiX) * (1.0f - phiY)) * vTL;
-                    v = fmaf(phiX * (1.0f - phiY), vTR, v);
-                    v = fmaf((1.0f - phiX) * phiY, vBL, v);
-                    v = fmaf(phiY * phiX, vBR, v);
-                    float dY = (-(1.0f - phiX)) * vTL;
-                    dY = fmaf(1.0f - phiX, vBL, dY);
-                    dY = fmaf(-phiX, vTR, dY);
-                    dY = fmaf(phiX, vBR, dY);
-                    float dX = (-(1.0f - phiY)) * vTL;
-                    dX = fmaf(1.0f - phiY, vTR, dX);
-                    dX = fmaf(-phiY, vBL, dX);
-                    dX = fmaf(phiY, vBR, dX);
-                    // quadrant: by integer index (VARIANT 0) or by displaced position (1, 2)
-                    unsigned quad;
-                    if constexpr (VARIANT == VFI_DEFOR_OFFSET) quad = (dj >= FS / 2 ? 2u : 0u) + (di >= FS / 2 ? 1u : 0u);
-                    else quad = ((qx >> k) & 1u) | (((qy >> k) & 1u) << 1);
-                    const float qgq = quad == 0 ? qg[0] : quad == 1 ? qg[1] : quad == 2 ? qg[2] : qg[3];
-                    const float kqq = quad == 0 ? kq[0] : quad == 1 ? kq[1] : quad == 2 ? kq[2] : kq[3];
-                    unsigned long long* cell = &win[crow[dj] + co[di]];
-                    if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
-                        atomicAdd(cell, (unsigned long long)__float2ll_rn(qgq * gctx.scale));
-                        const float upd = v;
+            for (int cc = 0; cc < DB_CH; ++cc) {
+                const float g = gv[cc];
+                qg[cc][0] = g * (1.0f - alpha) * (1.0f - beta); qg[cc][1] = g * alpha * (1.0f - beta);
+                qg[cc][2] = g * (1.0f - alpha) * beta;          qg[cc][3] = g * alpha * beta;
+                q[cc][0] = q[cc][1] = q[cc][2] = q[cc][3] = 0.0f;
+            }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) q[u] = quad == (unsigned)u ? q[u] + upd : q[u];
-                        goy[k] += g * kqq * dY;
-                        gox[k] += g * kqq * dX;
-                    } else {
-                        const float wg = wgt[k];
-                        atomicAdd(cell, (unsigned long long)__float2ll_rn(qgq * wg * gctx.scale));
-                        gfa[k] += qgq * v;
+            for (int k = 0; k < NT; ++k) {
+                const int dj = k / FS, di = k % FS;
+                int o = lb[k];
+                float phiY = phy[k], phiX = phx[k];
+                asm volatile("" : "+v"(o), "+v"(phiY), "+v"(phiX));    // (corner weights and addresses re-derived per pass: registers)
+                const float wTL = (1.0f - phiX) * (1.0f - phiY), wTR = phiX * (1.0f - phiY), wBL = (1.0f - phiX) * phiY, wBR = phiY * phiX;
+                // quadrant: by integer index (VARIANT 0) or by displaced position (1, 2)
+                unsigned quad;
+                if constexpr (VARIANT == VFI_DEFOR_OFFSET) quad = (dj >= FS / 2 ? 2u : 0u) + (di >= FS / 2 ? 1u : 0u);
+                else quad = ((qx >> k) & 1u) | (((qy >> k) & 1u) << 1);
+                const float kqq = quad == 0 ? kq[0] : quad == 1 ? kq[1] : quad == 2 ? kq[2] : kq[3];
+                const int cell = crow[dj] + co[di];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) q[u] = quad == (unsigned)u ? fmaf(v, wg, q[u]) : q[u];
-                        goy[k] += g * kqq * dY * wg;
-                        gox[k] += g * kqq * dX * wg;
+                for (int cc = 0; cc < DB_CH; ++cc) {
+                    if (cc < cn) {                          // (block-uniform)
+                        const float g = gv[cc];
+                        const float* t = wins + cc * DB_WIN_FLOATS + o;
+                        const float vTL = t[0], vTR = t[1], vBL = t[pitch], vBR = t[pitch + 1];
+                        float v = wTL * vTL;
+                        v = fmaf(wTR, vTR, v);
+                        v = fmaf(wBL, vBL, v);
+                        v = fmaf(wBR, vBR, v);
+                        float dY = (-(1.0f - phiX)) * vTL;
+                        dY = fmaf(1.0f - phiX, vBL, dY);
+                        dY = fmaf(-phiX, vTR, dY);
+                        dY = fmaf(phiX, vBR, dY);
+                        float dX = (-(1.0f - phiY)) * vTL;
+                        dX = fmaf(1.0f - phiY, vTR, dX);
+                        dX = fmaf(-phiY, vBL, dX);
+                        dX = fmaf(phiY, vBR, dX);
+                        const float qgq = quad == 0 ? qg[cc][0] : quad == 1 ? qg[cc][1] : quad == 2 ? qg[cc][2] : qg[cc][3];
+                        unsigned long long* cp = &cells[cc * ncell + cell];
+                        if constexpr (VARIANT == VFI_DEFOR_NOFILTER) {
+                            atomicAdd(cp, (unsigned long long)__float2ll_rn(qgq * gctx.scale));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) q[cc][u] = quad == (unsigned)u ? q[cc][u] + v : q[cc][u];
+                            goy[k] += g * kqq * dY;
+                            gox[k] += g * kqq * dX;
+                        } else {
+                            const float wg = wgt[k];
+                            atomicAdd(cp, (unsigned long long)__float2ll_rn(qgq * wg * gctx.scale));
+                            gfa[k] += qgq * v;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) q[cc][u] = quad == (unsigned)u ? fmaf(v, wg, q[cc][u]) : q[cc][u];
+                            goy[k] += g * kqq * dY * wg;
+                            gox[k] += g * kqq * dX * wg;
+                        }
                     }
                 }
-                {
-                    const float gamma = 1.0f - beta;
-                    float temp = gamma * (q[1] - q[0]);
-                    temp = fmaf(1.0f - gamma, q[3] - q[2], temp);
-                    gx = fmaf(g, temp, gx);
-                }
-                {
-                    const float gamma = 1.0f - alpha;
-                    float temp = gamma * (q[2] - q[0]);
-                    temp = fmaf(1.0f - gamma, q[3] - q[1], temp);
-                    gy = fmaf(g, temp, gy);
+            }
+#pragma unroll
+            for (int cc = 0; cc < DB_CH; ++cc) {
+                if (cc < cn) {
+                    const float g = gv[cc];
+                    {
+                        const float gamma = 1.0f - beta;
+                        float temp = gamma * (q[cc][1] - q[cc][0]);
+                        temp = fmaf(1.0f - gamma, q[cc][3] - q[cc][2], temp);
+                        gx = fmaf(g, temp, gx);
+                    }
+                    {
+                        const float gamma = 1.0f - alpha;
+                        float temp = gamma * (q[cc][2] - q[cc][0]);
+                        temp = fmaf(1.0f - gamma, q[cc][3] - q[cc][1], temp);
+                        gy = fmaf(g, temp, gy);
+                    }
                 }
             }
         }
