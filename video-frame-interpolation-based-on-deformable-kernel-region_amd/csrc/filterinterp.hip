@@ -68,11 +68,12 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 #define FB_TH 8
 #endif
 #ifndef FB_WAVES
-#define FB_WAVES 1                                  // (launch bound: waves per SIMD the kernel must fit)
+#define FB_WAVES 4                                  // (launch bound: waves per SIMD the kernel must fit -- two workgroups per CU)
 #endif
 #define FB_THREADS (FB_TW * FB_TH)
 #define FB_CH 3                                     // channels summed per pass
-#define FB_CELLS 7168                               // 64-bit cells of LDS (57,344 bytes)
+#define FB_CELLS 6144                               // 64-bit gradient cells per pass (49,152 bytes); half as many bytes of image windows
+#define FB_SLOT (FB_CELLS / FB_CH)                  // floats of one staged image window, at most (a multiple of the workgroup)
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
@@ -148,24 +149,29 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     gf[s2.c] = gy;
 }
 
-// fs == 4, image gradient through LDS (round 3).  The scatter above costs 16 global 64-bit atomics per pixel and channel
-// (110 M of them at 1080p, C = 3: 2 ms).  The addends are exact integers, so they can be summed in any grouping: a
-// workgroup of 1024 threads owns a 64x16 tile, takes the bounding box of its pixels' (clamped) taps and sums its addends
-// in a window of 64-bit cells in LDS (cheap integer atomics), three channels at a time; the window then goes to the
-// per-call scratch plane with ONE global atomic per non-zero cell -- (64 + 12) x (16 + 12) cells instead of 1024 x 16
-// addends per tile and channel.  Same integer sums, hence the same bits as the per-tap scatter; the 16 filter taps and the
-// 16 filter-gradient sums of the pixel live in registers across the channel loop (the general kernel re-reads the taps
-// and read-modify-writes the gradient cells in global memory once per channel and tap), summed in the same order from
-// the same starting value: the general kernel's bits.  A call with non-finite inputs (fp32 atomics: vfi_common.h) and a tile whose window does not fit keep the
-// per-tap scatter: the kernel flags them and fi_backward_ori, launched after it, does those tiles only.
+// fs == 4, image values and image gradient through LDS (round 3).  The per-tap kernel above gathers 16 image values per
+// pixel and channel from global memory and scatters 16 global 64-bit atomics (110 M of them at 1080p, C = 3).  Here a
+// workgroup owns a 64x8 tile and works through the channels three at a time.  The taps of `_ori` are undisplaced, so the
+// bounding box of the tile's (clamped) taps is both the window of image values it reads and the window of gradient cells
+// it writes: the three planes' windows are staged by LDS-DMA, the addends -- exact integers, summable in any grouping --
+// are added to 64-bit cells in LDS, and each non-zero cell leaves with ONE global atomic ((64 + 12) x (8 + 12) cells
+// instead of 512 x 16 addends per tile and channel).  Taps outside, the pass's channels inside; the 16 filter taps and
+// the 16 filter-gradient sums of the pixel live in registers (the per-tap kernel re-reads the taps and read-modify-writes
+// the gradient cells in global memory once per channel and tap).  Every sum keeps the per-tap kernel's order and starting
+// value: its bits.  A call with non-finite inputs (fp32 atomics: vfi_common.h) and a tile whose window does not fit are
+// flagged, and fi_backward_ori, launched after this kernel, does those tiles only.
+typedef __attribute__((address_space(3))) void* fb_lptr_t;
 
 __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     const float* __restrict__ gout, unsigned long long* __restrict__ acc, const int* __restrict__ hdr, int* __restrict__ tileflag,
     float* g2, float* g3, int channel, int h, int w, vfi_strides s1, vfi_strides s2, vfi_strides s3) {
     constexpr int fs = 4;
-    __shared__ unsigned long long cells[FB_CELLS];
-    __shared__ int box[4];
+    // one array: header (bounding box), gradient cells, image windows -- FB_CELLS of each for a pass
+    __shared__ __attribute__((aligned(16))) unsigned long long lds64[2 + FB_CELLS + FB_CELLS / 2];
+    int* box = reinterpret_cast<int*>(lds64);
+    unsigned long long* cells = lds64 + 2;
+    float* wins = reinterpret_cast<float*>(lds64 + 2 + FB_CELLS);
     const int tid = threadIdx.x;
     const int x = blockIdx.x * FB_TW + (tid & (FB_TW - 1));
     const int y = blockIdx.y * FB_TH + (tid >> 6);
@@ -200,11 +206,12 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
         }
     }
     __syncthreads();
-    const bool any = box[0] != INT_MAX;
-    if (!any) return;                                       // (workgroup-uniform: nothing in this tile has a gradient)
+    if (box[0] == INT_MAX) return;                          // (workgroup-uniform: nothing in this tile has a gradient)
     const int bx0 = box[0], by0 = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
     const int n = bw * bh;
-    if (gctx.nonfinite || n * min(FB_CH, channel) > FB_CELLS) {     // (workgroup-uniform) left to fi_backward_ori
+    const int hs = (int)s1.h;
+    static_assert(FB_SLOT % FB_THREADS == 0, "a window's last DMA instruction stays inside its slot");
+    if (gctx.nonfinite || n > FB_SLOT || (int64_t)h * hs * 4 > INT_MAX) {     // (workgroup-uniform) left to fi_backward_ori
         if (tid == 0) tileflag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
         return;
     }
@@ -220,22 +227,41 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
     int lrow[4];                                            // the window rows' first cells, less the box's first column
 #pragma unroll
     for (int k = 0; k < 4; ++k) lrow[k] = (ro[k] - by0) * bw - bx0;
+    const int plane_bytes = 4 * ((h - 1) * hs + w);
+    const float inv_bw = 1.0f / (float)bw;
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
     float gx = 0.0f, gy = 0.0f;
     for (int c0 = 0; c0 < channel; c0 += FB_CH) {
         const int cn = min(FB_CH, channel - c0);
-        for (int e = tid; e < n * cn; e += FB_THREADS) cells[e] = 0ull;
-        __syncthreads();
+        // ---- stage the pass's windows (element e of a window = cell e: row-major, bw per row, all inside the image), zero the
+        // cells, fetch gradoutput
         for (int cc = 0; cc < cn; ++cc) {
-            const int c = c0 + cc;
-            if (!valid) continue;
-            const float* p = img + (int64_t)c * s1.c;
-            const float g = gpx[(int64_t)c * s1.c];
-            const float qg[4] = { g * (1.0f - alpha) * (1.0f - beta), g * alpha * (1.0f - beta),
-                                  g * (1.0f - alpha) * beta,          g * alpha * beta };
-            float pv[16];
+            const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)(c0 + cc) * s1.c), 0, plane_bytes, 0x00020000);
+            float* slot = wins + cc * FB_SLOT + wave_first;
+            for (int e0 = 0; e0 < n; e0 += FB_THREADS) {
+                const int e = e0 + tid;
+                const int r = fi_row_of(e, inv_bw);
+                const int col = e - r * bw;
+                // (lanes past the window get an out-of-range offset: they write zeros, inside the window's own slot)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fb_lptr_t)(slot + e0), 4, e < n ? 4u * (unsigned)((by0 + r) * hs + bx0 + col) : 0x80000000u, 0, 0, 0);
+            }
+        }
+        for (int e = tid; e < n * cn; e += FB_THREADS) cells[e] = 0ull;
+        float gv[FB_CH];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) pv[k] = p[(int64_t)ro[k >> 2] * s1.h + co[k & 3]];
-            float q[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int cc = 0; cc < FB_CH; ++cc) gv[cc] = (valid && cc < cn) ? gpx[(int64_t)(c0 + cc) * s1.c] : 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (valid) {
+            float qg[FB_CH][4], q[FB_CH][4];
+#pragma unroll
+            for (int cc = 0; cc < FB_CH; ++cc) {
+                const float g = gv[cc];
+                qg[cc][0] = g * (1.0f - alpha) * (1.0f - beta); qg[cc][1] = g * alpha * (1.0f - beta);
+                qg[cc][2] = g * (1.0f - alpha) * beta;          qg[cc][3] = g * alpha * beta;
+                q[cc][0] = q[cc][1] = q[cc][2] = q[cc][3] = 0.0f;
+            }
+            // taps in the per-tap kernel's order (quadrant by quadrant), the pass's channels inside
 #pragma unroll
             for (int quad = 0; quad < 4; ++quad)
 #pragma unroll
@@ -243,21 +269,34 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
                         const int j = (quad >> 1) * 2 + jj, i = (quad & 1) * 2 + ii, k = j * fs + i;
-                        atomicAdd(&cells[cc * n + lrow[j] + co[i]], (unsigned long long)__float2ll_rn(qg[quad] * fv[k] * gctx.scale));
-                        gf16[k] += qg[quad] * pv[k];
-                        q[quad] = fmaf(pv[k], fv[k], q[quad]);
+                        const int cell = lrow[j] + co[i];
+#pragma unroll
+                        for (int cc = 0; cc < FB_CH; ++cc) {
+                            if (cc < cn) {                  // (workgroup-uniform)
+                                const float pv = wins[cc * FB_SLOT + cell];
+                                atomicAdd(&cells[cc * n + cell], (unsigned long long)__float2ll_rn(qg[cc][quad] * fv[k] * gctx.scale));
+                                gf16[k] += qg[cc][quad] * pv;
+                                q[cc][quad] = fmaf(pv, fv[k], q[cc][quad]);
+                            }
+                        }
                     }
-            {   // flow gradient by quadrant differences (:2965-3102)
-                const float gamma = 1.0f - beta;
-                float temp = gamma * (q[1] - q[0]);
-                temp = fmaf(1.0f - gamma, q[3] - q[2], temp);
-                gx = fmaf(g, temp, gx);
-            }
-            {
-                const float gamma = 1.0f - alpha;
-                float temp = gamma * (q[2] - q[0]);
-                temp = fmaf(1.0f - gamma, q[3] - q[1], temp);
-                gy = fmaf(g, temp, gy);
+#pragma unroll
+            for (int cc = 0; cc < FB_CH; ++cc) {
+                if (cc < cn) {
+                    const float g = gv[cc];
+                    {   // flow gradient by quadrant differences (:2965-3102)
+                        const float gamma = 1.0f - beta;
+                        float temp = gamma * (q[cc][1] - q[cc][0]);
+                        temp = fmaf(1.0f - gamma, q[cc][3] - q[cc][2], temp);
+                        gx = fmaf(g, temp, gx);
+                    }
+                    {
+                        const float gamma = 1.0f - alpha;
+                        float temp = gamma * (q[cc][2] - q[cc][0]);
+                        temp = fmaf(1.0f - gamma, q[cc][3] - q[cc][1], temp);
+                        gy = fmaf(g, temp, gy);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -269,7 +308,7 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
                 atomicAdd(&gimg[(int64_t)(c0 + cc) * h * w + (int64_t)(by0 + cy) * w + bx0 + cx], v);
             }
         }
-        __syncthreads();                                    // (the next pass zeroes the cells)
+        __syncthreads();                                    // (the next pass overwrites windows and cells)
     }
     if (valid) {
 #pragma unroll
