@@ -73,7 +73,6 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 #define FB_THREADS (FB_TW * FB_TH)
 #define FB_CH 3                                     // channels summed per pass
 #define FB_CELLS 6144                               // 64-bit gradient cells per pass (49,152 bytes); half as many bytes of image windows
-#define FB_SLOT (FB_CELLS / FB_CH)                  // floats of one staged image window, at most (a multiple of the workgroup)
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
@@ -159,7 +158,8 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
 // the 16 filter-gradient sums of the pixel live in registers (the per-tap kernel re-reads the taps and read-modify-writes
 // the gradient cells in global memory once per channel and tap).  Every sum keeps the per-tap kernel's order and starting
 // value: its bits.  A call with non-finite inputs (fp32 atomics: vfi_common.h) and a tile whose window does not fit are
-// flagged, and fi_backward_ori, launched after this kernel, does those tiles only.
+// flagged, and fi_backward_ori, launched after this kernel, does those tiles only.  A tile with a large window takes two
+// channels, or one, per pass.
 typedef __attribute__((address_space(3))) void* fb_lptr_t;
 
 __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
@@ -210,8 +210,11 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
     const int bx0 = box[0], by0 = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
     const int n = bw * bh;
     const int hs = (int)s1.h;
-    static_assert(FB_SLOT % FB_THREADS == 0, "a window's last DMA instruction stays inside its slot");
-    if (gctx.nonfinite || n > FB_SLOT || (int64_t)h * hs * 4 > INT_MAX) {     // (workgroup-uniform) left to fi_backward_ori
+    // channels per pass: as many (at most FB_CH) as fit the cells and the window slots -- a slot is the window rounded up to
+    // whole DMA instructions, so that a window's last instruction stays inside its slot
+    const int slot_floats = (n + FB_THREADS - 1) & ~(FB_THREADS - 1);
+    const int pc = min(FB_CH, FB_CELLS / slot_floats);
+    if (gctx.nonfinite || pc == 0 || (int64_t)h * hs * 4 > INT_MAX) {     // (workgroup-uniform) left to fi_backward_ori
         if (tid == 0) tileflag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
         return;
     }
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
     const float inv_bw = 1.0f / (float)bw;
     const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
     float gx = 0.0f, gy = 0.0f;
-    for (int c0 = 0; c0 < channel; c0 += FB_CH) {
-        const int cn = min(FB_CH, channel - c0);
+    for (int c0 = 0; c0 < channel; c0 += pc) {
+        const int cn = min(pc, channel - c0);
         // ---- stage the pass's windows (element e of a window = cell e: row-major, bw per row, all inside the image), zero the
         // cells, fetch gradoutput
         for (int cc = 0; cc < cn; ++cc) {
             const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)(c0 + cc) * s1.c), 0, plane_bytes, 0x00020000);
-            float* slot = wins + cc * FB_SLOT + wave_first;
+            float* slot = wins + cc * slot_floats + wave_first;
             for (int e0 = 0; e0 < n; e0 += FB_THREADS) {
                 const int e = e0 + tid;
                 const int r = fi_row_of(e, inv_bw);
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(FB_THREADS, FB_WAVES) void fi_backward_ori4_lds(
 #pragma unroll
                         for (int cc = 0; cc < FB_CH; ++cc) {
                             if (cc < cn) {                  // (workgroup-uniform)
-                                const float pv = wins[cc * FB_SLOT + cell];
+                                const float pv = wins[cc * slot_floats + cell];
                                 atomicAdd(&cells[cc * n + cell], (unsigned long long)__float2ll_rn(qg[cc][quad] * fv[k] * gctx.scale));
                                 gf16[k] += qg[cc][quad] * pv;
                                 q[cc][quad] = fmaf(pv, fv[k], q[cc][quad]);

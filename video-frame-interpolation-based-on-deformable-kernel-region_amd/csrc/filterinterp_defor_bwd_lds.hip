@@ -136,7 +136,8 @@ __global__ __launch_bounds__(DB_THREADS, 2) void fi_backward_defor_lds(
     const int gx0 = box[4], gy0 = box[5], gw = box[6] - box[4] + 1, ncell = gw * (box[7] - box[5] + 1);
     const int pitch = (bw + 31) & ~31;                      // (a multiple of the 32 banks: fi_pitch_for's fp32 case)
     const int64_t n64 = (int64_t)pitch * bh;
-    if (gctx.nonfinite || box[8] || n64 > DB_WIN_FLOATS || ncell * min(DB_CH, channel) > DB_CELLS) {      // (block-uniform)
+    const int pc = min(DB_CH, DB_CELLS / max(ncell, 1));   // channels per pass: as many as the gradient cells allow
+    if (gctx.nonfinite || box[8] || n64 > DB_WIN_FLOATS || pc == 0) {      // (block-uniform)
         if (tid == 0) tileflag[tile] = 1;                   // left to fi_backward_defor<VARIANT, false, 4>
         return;
     }
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(DB_THREADS, 2) void fi_backward_defor_lds(
     const float kq[4] = { (1.0f - alpha) * (1.0f - beta), alpha * (1.0f - beta), (1.0f - alpha) * beta, alpha * beta };
     float gx = 0.0f, gy = 0.0f;
 
-    for (int c0 = 0; c0 < channel; c0 += DB_CH) {
-        const int cn = min(DB_CH, channel - c0);
+    for (int c0 = 0; c0 < channel; c0 += pc) {
+        const int cn = min(pc, channel - c0);
         // ---- stage the windows of the pass (element e = tid + k * 256 of a window, row-major with `pitch`; pad elements
         // and rows past the last get an out-of-range offset: zero, no memory traffic), zero the cells, fetch gradoutput
         for (int cc = 0; cc < cn; ++cc) {
