@@ -140,7 +140,8 @@ __global__ __launch_bounds__(IB_THREADS) void interp_backward_lds(
     if (box[0] == INT_MAX) return;                          // (workgroup-uniform: nothing in this tile has a gradient)
     const int bx0 = box[0], by0 = box[1], bw = box[2] - box[0] + 1, bh = box[3] - box[1] + 1;
     const int n = bw * bh;
-    if (gctx.nonfinite || n * min(IB_CH, channel) > IB_CELLS) {     // (workgroup-uniform) left to interp_backward
+    const int pc = min(IB_CH, IB_CELLS / n);                // channels per pass: as many as the cells allow
+    if (gctx.nonfinite || pc == 0) {                        // (workgroup-uniform) left to interp_backward
         if (tid == 0) tileflag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
         return;
     }
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(IB_THREADS) void interp_backward_lds(
     const float gam_y = (float)Bm - y2;         // (:161)
     const float gam_x = (float)R - x2;          // (:181)
     float botx = 0.0f, boty = 0.0f;
-    for (int c0 = 0; c0 < channel; c0 += IB_CH) {
-        const int cn = min(IB_CH, channel - c0);
+    for (int c0 = 0; c0 < channel; c0 += pc) {
+        const int cn = min(pc, channel - c0);
         for (int e = tid; e < n * cn; e += IB_THREADS) cells[e] = 0ull;
         __syncthreads();
         for (int cc = 0; cc < cn && valid; ++cc) {
