@@ -71,13 +71,18 @@ def parse(argv=None):
                     help="slowmo1080: f16 = BASELINE.json configs[2], frames / context / correlation features and their "
                          "outputs stored as fp16, flows, filters, depth and all arithmetic fp32")
     ap.add_argument("--vimeo-batch", type=int, default=3, help="vimeo64: triplets per call (the reference's PWC-Net allows 3)")
-    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
-                    help="slowmo1080: 2 = one HIP stream per flow direction (the two directions are independent chains of "
-                         "correlations, projections and warps); 1 = one stream, the reference's call order")
+    ap.add_argument("--streams", type=int, default=None, choices=(1, 2, 3, 4, 6, 8),
+                    help="slowmo1080: 2 (or more) = one HIP stream per flow direction (the two directions are independent chains "
+                         "of correlations, projections and warps); 1 = one stream, the reference's call order.  vimeo64: the "
+                         "batches of a step dealt over that many streams (branches of the step's graph).  Default: 1 for "
+                         "slowmo1080, 4 for vimeo64")
     ap.add_argument("--no-graph", action="store_true", help="vimeo64: eager calls instead of one captured HIP graph per step")
     ap.add_argument("--stub-step", type=float, default=None, metavar="SECONDS",
                     help="plumbing test: a step is a sleep of SECONDS, no GPU is touched (tests/test_abi_and_host.py)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.streams is None:
+        args.streams = 4 if args.workload == "vimeo64" else 1
+    return args
 
 
 # ------------------------------------------------------------------------------------------- workloads
@@ -199,14 +204,25 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
     sizes = [min(bmax, len(mine) - k) for k in range(0, len(mine), bmax)]
     pairs = [VimeoPair(torch, S, dev, S.SEED + 1000 + mine[sum(sizes[:j])], batch=sizes[j]) for j in range(len(sizes))]
 
+    # --streams N: the batches are independent (every batch has its own count / proj / output tensors, the library one
+    # projection workspace per stream), so they can be dealt over N streams -- N parallel branches of the step's graph.
+    # The launches of a 320x512 batch fill a fraction of the GPU each.
+    branches = [torch.cuda.Stream(dev) for _ in range(args.streams)] if args.streams > 1 else []
+
     def step(_i):
-        for p in pairs:
-            for d in range(2):
-                for a, b in p.corr[d]:
-                    cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
-            for d in range(2):                              # DAIN.FlowProject + DAIN.FilterInterpolate (DAIN.py:218-238)
-                assert cabi.flowprojection_forward(p.flows[d], p.count, p.proj, 1) == 0
-                assert cabi.filterinterp_forward_ori(p.frames[d], p.proj, p.filters[d], p.out[d]) == 0
+        cur = torch.cuda.current_stream(dev)
+        for br in branches:
+            br.wait_stream(cur)
+        for j, p in enumerate(pairs):
+            with torch.cuda.stream(branches[j % len(branches)] if branches else cur):
+                for d in range(2):
+                    for a, b in p.corr[d]:
+                        cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+                for d in range(2):                          # DAIN.FlowProject + DAIN.FilterInterpolate (DAIN.py:218-238)
+                    assert cabi.flowprojection_forward(p.flows[d], p.count, p.proj, 1) == 0
+                    assert cabi.filterinterp_forward_ori(p.frames[d], p.proj, p.filters[d], p.out[d]) == 0
+        for br in branches:
+            cur.wait_stream(br)
 
     for i in range(max(1, args.warmup)):
         step(i)
@@ -243,7 +259,8 @@ def run_vimeo64(args, torch, cabi, runner, S, dev, rank, world):
                                "2 FlowProjection(fillhole) + 2 FilterInterpolation(C=3)), B<=%d per call; 1 frame per pair"
                                % (h, w, bmax),
                    "pairs": n_pairs, "batches_per_rank_0": sizes, "pairs_per_rank": [len(runner.shard_pairs(n_pairs, r, world)) for r in range(world)],
-                   "filter_size": 4, "launch": launch, "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
+                   "filter_size": 4, "launch": launch, "streams": args.streams,
+                   "parallelism": "replicas x%d (pairs sharded, no collective)" % world},
     }
 
 
