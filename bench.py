@@ -311,8 +311,8 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
     count2, out_ctx2, out_img2 = torch.empty_like(wl.count), torch.empty_like(wl.out_ctx), torch.empty_like(wl.out_img)
 
     def step2(i, record=False):
-        # (direction 1 first: its stream forks from what the current stream holds BEFORE this step's direction-0 launches)
-        for d, cnt, oc, oi in ((1, count2, out_ctx2, out_img2), (0, wl.count, wl.out_ctx, wl.out_img)):
+        lanes.fork()
+        for d, cnt, oc, oi in ((0, wl.count, wl.out_ctx, wl.out_img), (1, count2, out_ctx2, out_img2)):
             with lanes.direction(d):
                 for a, b in wl.corr[d]:
                     cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)

@@ -378,7 +378,8 @@ def test_direction_streams_helper(torch_mod, cabi):
     lanes = fused.DirectionStreams(dev)
     for _ in range(5):
         got = {}
-        for d in (1, 0):
+        lanes.fork()
+        for d in (0, 1):
             with lanes.direction(d):
                 chain(d, got)
         lanes.join()

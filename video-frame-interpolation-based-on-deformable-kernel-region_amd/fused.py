@@ -23,8 +23,9 @@ class DirectionStreams:
     `count` plane and output tensors.
 
         ds = DirectionStreams(device)
+        ds.fork()                       # the side stream starts after what the current stream holds NOW (the inputs)
         for d in (0, 1):
-            with ds.direction(d):       # d = 0: the current stream; d = 1: the side stream, ordered after the current one
+            with ds.direction(d):       # d = 0: the current stream; d = 1: the side stream
                 ...                     # direction d's calls
         ds.join()                       # the current stream continues when both are done
     """
@@ -34,14 +35,14 @@ class DirectionStreams:
         self.side = torch.cuda.Stream(device)
         self._forked = False
 
+    def fork(self):
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        self._forked = True
+
     def direction(self, d):
-        main = torch.cuda.current_stream(self.device)
-        if d == 0:
-            return torch.cuda.stream(main)
         if not self._forked:
-            self.side.wait_stream(main)     # what the current stream has queued so far (inputs, the previous step) comes first
-            self._forked = True
-        return torch.cuda.stream(self.side)
+            raise RuntimeError("DirectionStreams.fork() first: the side stream must be ordered after the inputs")
+        return torch.cuda.stream(torch.cuda.current_stream(self.device) if d == 0 else self.side)
 
     def join(self):
         if self._forked:
