@@ -553,10 +553,40 @@ def shared_window_measurement(torch, cabi, wl, dev, args):
     ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     nbytes = (2 * nt + 16 + 196 + nt * 196) * 4.0 * wl.px
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "fi_forward_ori_multi<3> (C=196: one staged window, three flows, three outputs)",
-            "avg_launch_ms": round(ms, 4), "ms_per_output": round(ms / nt, 4), "algorithmic_bytes_per_launch": nbytes,
-            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "ms_per_step": round(step_ms, 4), "frames_per_s": round(nt / (step_ms * 1e-3), 1)}
+    res = {"kernel": "fi_forward_ori_multi<3> (C=196: one staged window, three flows, three outputs)",
+           "avg_launch_ms": round(ms, 4), "ms_per_output": round(ms / nt, 4), "algorithmic_bytes_per_launch": nbytes,
+           "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "ms_per_step": round(step_ms, 4), "frames_per_s": round(nt / (step_ms * 1e-3), 1)}
+
+    # ... and with one HIP stream per flow direction as well (fused.DirectionStreams; see two_streams)
+    from vfidkr_amd import fused
+    lanes = fused.DirectionStreams(dev)
+    count2, img2 = torch.empty_like(wl.count), torch.empty_like(wl.out_img)
+    outs2 = [torch.empty_like(wl.out_ctx) for _ in range(nt)]
+
+    def step_lanes(i):
+        lanes.fork()
+        for d, cnt, oc, oi in ((0, wl.count, outs, wl.out_img), (1, count2, outs2, img2)):
+            with lanes.direction(d):
+                for a, b in wl.corr[d]:
+                    cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+                for ti in range(nt):
+                    assert cabi.depthflowprojection_forward(wl.flows[d][ti], wl.depth[d], cnt, projs[d][ti], 1) == 0
+                assert cabi.filterinterp_forward_ori_multi(wl.ctx[d], projs[d], wl.filters[d], oc) == 0
+                for ti in range(nt):
+                    assert cabi.filterinterp_forward_ori(wl.frames[d], projs[d][ti], wl.filters[d], oi, direct=args.direct) == 0
+        lanes.join()
+
+    for i in range(2):
+        step_lanes(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_lanes(i)
+    torch.cuda.synchronize(dev)
+    lanes_ms = (time.perf_counter() - t0) / steps * 1e3
+    res["two_streams"] = {"ms_per_step": round(lanes_ms, 4), "frames_per_s": round(nt / (lanes_ms * 1e-3), 1)}
+    return res
 
 
 def cpu_baseline(torch, cabi, wl, dev, args):
