@@ -133,6 +133,19 @@ int vfi_flowprojection_backward(const float* input1, const float* count, const f
                                 vfi_strides s1, vfi_strides sc,
                                 vfi_stream_t stream);
 
+/* FlowProject(inputs, depth) of the networks (networks/DAIN.py:533-539, networks/DAIN_slowmotion.py:301-307 -- the reference
+ * loops over the list, one FlowProjectionModule call per flow, and does so for both directions back to back,
+ * DAIN.py:215-220 / DAIN_slowmotion.py:156-159): the whole list in ONE launch triple (per 8 items), so that the three
+ * dependent launches of a projection are paid once per list, not once per flow.  inputs1 / counts / outputs: HOST arrays of
+ * nitems device pointers, item i = [batch,2,h,w] flow -> [batch,1,h,w] count + [batch,2,h,w] output; all items share
+ * shape and strides (s1: flows and outputs, sc: counts).  Every item needs its own count and output (they are written
+ * concurrently: two equal pointers are refused with VFI_ERR_SHAPE).  Results per item: vfi_flowprojection_forward's, bit for
+ * bit.  The workspace must cover nitems * batch frames: vfi_projection_reserve(nitems * batch, h, w, stream) before a capture. */
+int vfi_flowprojection_forward_batch(const float* const* inputs1, float* const* counts, float* const* outputs,
+                                     int nitems, int batch, int h, int w, int fillhole,
+                                     vfi_strides s1, vfi_strides sc,
+                                     vfi_stream_t stream);
+
 /* Make the projection workspace of `stream` large enough for [batch, *, h, w] frames (both projections and
  * their _up4 forms; h, w are the full-resolution sizes).  Allocates, so call it outside a capture. */
 int vfi_projection_reserve(int batch, int h, int w, vfi_stream_t stream);
@@ -149,6 +162,13 @@ int vfi_depthflowprojection_forward(const float* input1, const float* input2,
                                     int batch, int h, int w, int fillhole,
                                     vfi_strides s1, vfi_strides s2, vfi_strides sc,
                                     vfi_stream_t stream);
+/* the list form (see vfi_flowprojection_forward_batch); inputs2[i] is item i's depth weight [batch,1,h,w] with strides s2 --
+ * items may share one (DAIN_slowmotion projects every time offset of a direction with that direction's depth) */
+int vfi_depthflowprojection_forward_batch(const float* const* inputs1, const float* const* inputs2,
+                                          float* const* counts, float* const* outputs,
+                                          int nitems, int batch, int h, int w, int fillhole,
+                                          vfi_strides s1, vfi_strides s2, vfi_strides sc,
+                                          vfi_stream_t stream);
 int vfi_depthflowprojection_backward(const float* input1, const float* input2,
                                      const float* count, const float* output,
                                      const float* gradoutput,

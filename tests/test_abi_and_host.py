@@ -293,6 +293,14 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
         for b in blocks:
             if b["is_header"]:
                 b["loop"] = b["label"]
+        for b in blocks:
+            # what follows the branch back to the loop's header in the same text block is the loop's exit path (an
+            # unlabelled fall-through block), not the loop
+            if b["loop"]:
+                for k, i in enumerate(b["ins"]):
+                    if re.match(r"s_c?branch\w*\s+\.L" + re.escape(b["loop"]) + r"\b", i):
+                        b["ins"] = b["ins"][:k + 1]
+                        break
         is_dma = lambda i: i.startswith("buffer_load") and " lds" in i      # noqa: E731
         dma_loops = {b["loop"] for b in blocks if b["loop"] and any(is_dma(i) for i in b["ins"])}
         # a loop whose every vmcnt wait is vmcnt(0) keeps nothing in flight across its waits (the two-slot rings of the

@@ -1,0 +1,218 @@
+"""`-m gpu` parity tests (round 4): the list form of the projections (`FlowProject(inputs, depth)` in one launch triple),
+and the chained harness-level check -- FlowProject -> FilterInterpolate -> blend -> uint8 frame on the GPU only against the
+same chain on the oracle only, PSNR as demo_MiddleBury.py:370-378 with SURVEY 8(d)'s thresholds."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import close, cpu, gpu, smooth_flow, f32, torch_mod, cabi  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _nan(torch, *shape):
+    return torch.full(shape, float("nan"), device="cuda:0")
+
+
+@pytest.mark.parametrize("n,B,H,W", [(2, 1, 32, 48), (3, 2, 17, 70), (6, 1, 40, 200), (9, 1, 33, 130), (1, 1, 1, 1)])
+@pytest.mark.parametrize("fillhole", [0, 1])
+@pytest.mark.parametrize("depth_mode", ["none", "shared", "per_item"])
+def test_projection_batch_equals_single_calls(torch_mod, cabi, oracle, n, B, H, W, fillhole, depth_mode):
+    """Every item of a batched call == the single call on that item, bit for bit (same kernels, same tile work), and
+    == the oracle within the single call's tolerances.  n = 9 goes as 8 + 1 items; depth shared by all items or one
+    per item (DAIN_slowmotion: one per direction)."""
+    torch = torch_mod
+    rng = np.random.default_rng(n * 1000 + H * W)
+    flows = [(smooth_flow(rng, B, H, W, 3.0) * f32(0.5 + 0.25 * i)).astype(f32) if H > 1 else np.zeros((B, 2, H, W), f32)
+             for i in range(n)]
+    depths = None
+    if depth_mode == "shared":
+        d = rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32)
+        depths = [d] * n
+    elif depth_mode == "per_item":
+        depths = [rng.uniform(0.1, 1.0, (B, 1, H, W)).astype(f32) for _ in range(n)]
+    gflows = [gpu(torch, f) for f in flows]
+    gdepths = None
+    if depths is not None:
+        shared = gpu(torch, depths[0])
+        gdepths = shared if depth_mode == "shared" else [gpu(torch, d) for d in depths]
+    counts = [_nan(torch, B, 1, H, W) for _ in range(n)]
+    outs = [_nan(torch, B, 2, H, W) for _ in range(n)]
+    assert cabi.flowprojection_forward_batch(gflows, counts, outs, fillhole, gdepths) == 0
+    for i in range(n):
+        c1, o1 = _nan(torch, B, 1, H, W), _nan(torch, B, 2, H, W)
+        if depths is None:
+            assert cabi.flowprojection_forward(gflows[i], c1, o1, fillhole) == 0
+            ref, rcount = oracle.flowproj_fwd(flows[i], fillhole)
+            assert np.array_equal(cpu(counts[i]), rcount)
+            assert np.abs(cpu(outs[i]) - ref).max() <= 1e-4
+        else:
+            gd = gdepths if depth_mode == "shared" else gdepths[i]
+            assert cabi.depthflowprojection_forward(gflows[i], gd, c1, o1, fillhole) == 0
+            ref, rcount = oracle.depthflowproj_fwd(flows[i], depths[i], fillhole)
+            assert np.array_equal(cpu(counts[i]) > 0, rcount > 0)
+            assert close(cpu(counts[i]), rcount, 1e-4) and close(cpu(outs[i]), ref, 1e-4)
+        assert torch.equal(counts[i], c1) and torch.equal(outs[i], o1), i
+
+
+def test_projection_batch_mixed_fields_and_fallback(torch_mod, cabi, oracle):
+    """Items of one call on very different fields: zero, smooth, uniform(-1,1), all-out-of-frame and a +-W/2 field that
+    sends the WHOLE call down the atomic fallback; dyadic values, so every sum is exact in any order: bit-exact with the
+    oracle on both paths.  Then a normal call on the same stream: the fallback's scratch planes were cleaned."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    B, H, W = 1, 48, 200
+    q = lambda a: (np.round(a * 8) / 8).astype(f32)     # noqa: E731
+    fields = [np.zeros((B, 2, H, W), f32), q(smooth_flow(rng, B, H, W, 4.0)), q(rng.uniform(-1, 1, (B, 2, H, W))),
+              np.full((B, 2, H, W), 1000.0, f32)]
+    wild = q(rng.uniform(-W / 2, W / 2, (B, 2, H, W)))
+    for fl in (fields, fields + [wild], fields):
+        n = len(fl)
+        counts = [_nan(torch, B, 1, H, W) for _ in range(n)]
+        outs = [_nan(torch, B, 2, H, W) for _ in range(n)]
+        assert cabi.flowprojection_forward_batch([gpu(torch, f) for f in fl], counts, outs, 1) == 0
+        for i in range(n):
+            ref, rcount = oracle.flowproj_fwd(fl[i], 1)
+            assert np.array_equal(cpu(counts[i]), rcount) and np.array_equal(cpu(outs[i]), ref), (n, i)
+
+
+def test_projection_batch_binding_checks(torch_mod, cabi):
+    torch = torch_mod
+    B, H, W = 1, 16, 64
+    fl = [torch.zeros((B, 2, H, W), device="cuda:0") for _ in range(2)]
+    cn = [torch.zeros((B, 1, H, W), device="cuda:0") for _ in range(2)]
+    out = [torch.zeros((B, 2, H, W), device="cuda:0") for _ in range(2)]
+    assert cabi.flowprojection_forward_batch(fl, cn, out, 1) == 0
+    assert cabi.flowprojection_forward_batch(fl, [cn[0], cn[0]], out, 1) == 1          # shared count plane
+    assert cabi.flowprojection_forward_batch(fl, cn, [out[0], out[0]], 1) == 1          # shared output
+    assert cabi.flowprojection_forward_batch(fl, cn[:1], out, 1) == 1                   # list lengths
+    assert cabi.flowprojection_forward_batch([fl[0], torch.zeros((B, 2, H, W + 4), device="cuda:0")], cn, out, 1) == 1
+    assert cabi.flowprojection_forward_batch([], [], [], 1) == 1
+    with pytest.raises(RuntimeError):
+        cabi.flowprojection_forward_batch([f.cpu() for f in fl], cn, out, 1)
+
+
+def test_projection_batch_1080p_and_graph_replay(torch_mod, cabi, oracle):
+    """The slow-motion step's six DepthFlowProjection calls (2 directions x 3 time offsets, each direction its own depth)
+    as ONE call at 1152x1984: bit-identical with the six single calls, run-to-run bitwise, replayable from a HIP graph
+    (pointer tables are kernel arguments), one item against the oracle."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import synthetic as S, fused
+    H, W = S.padded_size(1080, 1920)
+    gen = S.generator()
+    base = [S.flow(1, H, W, 8.0, gen, "smooth") for _ in range(2)]
+    depth = [S.depth_weight(1, H, W, gen) for _ in range(2)]
+    times = (0.25, 0.5, 0.75)
+    flows = [[(base[d] * (2.0 * t)).contiguous().cuda() for t in times] for d in range(2)]
+    gdepth = [d.cuda() for d in depth]
+    flat = flows[0] + flows[1]
+    dlist = [gdepth[0]] * 3 + [gdepth[1]] * 3
+    single = []
+    for f, d in zip(flat, dlist):
+        c, o = _nan(torch, 1, 1, H, W), _nan(torch, 1, 2, H, W)
+        assert cabi.depthflowprojection_forward(f, d, c, o, 1) == 0
+        single.append((c, o))
+    counts = [_nan(torch, 1, 1, H, W) for _ in flat]
+    outs = [_nan(torch, 1, 2, H, W) for _ in flat]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert cabi.projection_reserve(len(flat), H, W) == 0
+        assert cabi.flowprojection_forward_batch(flat, counts, outs, 1, dlist) == 0
+        s.synchronize()
+        for i, (c, o) in enumerate(single):
+            assert torch.equal(counts[i], c) and torch.equal(outs[i], o), i
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            assert cabi.flowprojection_forward_batch(flat, counts, outs, 1, dlist) == 0
+        for _ in range(2):
+            for c, o in zip(counts, outs):
+                c.fill_(float("nan")), o.fill_(float("nan"))
+            g.replay()
+            s.synchronize()
+            for i, (c, o) in enumerate(single):
+                assert torch.equal(counts[i], c) and torch.equal(outs[i], o), i
+        del g
+    torch.cuda.synchronize()
+    ref, rcount = oracle.depthflowproj_fwd(flat[4].cpu().numpy(), depth[1].numpy(), 1)
+    assert np.array_equal(cpu(counts[4]) > 0, rcount > 0)
+    assert close(cpu(counts[4]), rcount, 1e-4) and close(cpu(outs[4]), ref, 1e-4)
+    # the host mirror of the networks' two FlowProject calls
+    both = fused.FlowProject_directions(flows, gdepth)
+    torch.cuda.synchronize()
+    for d in range(2):
+        for ti in range(3):
+            assert torch.equal(both[d][ti], single[3 * d + ti][1])
+    # FlowProjection (no depth), both directions of DAIN x2 in one call == two calls
+    two = fused.FlowProject_directions([[flows[0][1]], [flows[1][1]]])
+    for d in range(2):
+        c, o = _nan(torch, 1, 1, H, W), _nan(torch, 1, 2, H, W)
+        assert cabi.flowprojection_forward(flows[d][1], c, o, 1) == 0
+        assert torch.equal(two[d][0], o)
+
+
+@pytest.mark.parametrize("model", ["smooth", "quarter"])
+def test_chain_psnr_1080p(torch_mod, cabi, oracle, model):
+    """SURVEY 8(d) harness-level parity at 1152x1984: one interpolated frame of DAIN_slowmotion made by the GPU chain only
+    (FlowProject of both directions -> FilterInterpolate -> blend -> uint8 frame) against the oracle chain only
+    (oracle/chain.py), same inputs.  The projected flows differ in the last bits (sum order), and a difference that
+    straddles an integer moves a warp window by a whole pixel: PSNR of the uint8 frames (demo_MiddleBury.py:370-378) is the
+    measure.  fp32 >= 60 dB; fp16 storage (frames and warped frames stored as half, BASELINE configs[2]) >= 45 dB."""
+    torch = torch_mod
+    import vfidkr_amd  # noqa: F401
+    from vfidkr_amd import synthetic as S, fused
+    from oracle import chain
+    h, w = 1080, 1920
+    H, W = S.padded_size(h, w)
+    left, right, top, bottom = fused.padding_for(h, w)
+    assert (H, W) == (h + top + bottom, w + left + right)
+    gen = S.generator(4242)
+    t = 0.25
+    frames = [S.frames(1, H, W, gen) for _ in range(2)]
+    filters = [S.filters(1, H, W, gen) for _ in range(2)]
+    depths = [S.depth_weight(1, H, W, gen) for _ in range(2)]
+    base = [S.flow(1, H, W, 8.0, gen, model) for _ in range(2)]
+    flows = [(base[0] * (2.0 * t)).contiguous(), (base[1] * (2.0 * (1.0 - t))).contiguous()]
+    ctx = [S.context(1, 6, H, W, gen) for _ in range(2)]
+    ref = chain.unit([f.numpy() for f in frames], [f.numpy() for f in flows], [d.numpy() for d in depths],
+                     [k.numpy() for k in filters], t, h, w, left, top, nthreads=8, ctx=[c.numpy() for c in ctx])
+
+    gfr, gfl, gd, gk = ([x.cuda() for x in v] for v in (frames, flows, depths, filters))
+    proj = fused.FlowProject_directions([[gfl[0]], [gfl[1]]], gd)
+    p0, p2 = proj[0][0], proj[1][0]
+    blend, _, _ = fused.FilterInterpolate(gfr[0], gfr[1], [p0, p2], gk, 16, t)
+    u8 = fused.padded_to_frames(blend, h, w, (left, right, top, bottom))
+    gctx = fused.FilterInterpolate_ctx_all(ctx[0].cuda(), ctx[1].cuda(), [[p0], [p2]], gk)[0]
+    torch.cuda.synchronize()
+
+    # the projections: within the op's tolerance; how many window origins a last-bit difference moves
+    flips, dmax = 0, 0.0
+    for d, p in enumerate((p0, p2)):
+        assert close(cpu(p), ref["proj"][d], 1e-4)
+        flips += chain.int_flips(cpu(p), ref["proj"][d])
+        dmax = max(dmax, float(np.abs(cpu(p) - ref["proj"][d]).max()))
+    psnr = chain.psnr_u8(cpu(u8), ref["u8"])
+    differing = int(np.count_nonzero(cpu(u8) != ref["u8"]))
+    print("chain parity (%s): PSNR %.2f dB, %d of %d uint8 values differ, %d window origins moved"
+          % (model, psnr, differing, ref["u8"].size, flips))
+    assert psnr >= 60.0
+    # a moved window origin changes that pixel only; everywhere else the bilinear fractions differ in their last bits,
+    # which can move a value across a rounding boundary by one level at most
+    big = np.abs(cpu(u8).astype(np.int32) - ref["u8"].astype(np.int32)) > 1
+    assert np.count_nonzero(np.any(big, axis=3)) <= flips
+    # the context warps likewise: a difference d of the projected flow moves a bilinear fraction by d, i.e. the value by at
+    # most d x (the four quadrant sums' spread: 16 taps of weight < 1 on N(0, 1) values)
+    for d in range(2):
+        bad = np.any(np.abs(cpu(gctx[d]) - ref["ctx"][d]) > (1e-5 + 100.0 * dmax) * np.maximum(1.0, np.abs(ref["ctx"][d])), axis=1)
+        assert np.count_nonzero(bad) <= flips
+
+    # fp16 storage: frames in, warped frames out as half; flows, filters, depth and all arithmetic fp32
+    o0 = torch.empty((1, 3, H, W), device="cuda:0", dtype=torch.float16)
+    o2 = torch.empty_like(o0)
+    assert cabi.filterinterp_forward_ori_f16(gfr[0].half(), p0, gk[0], o0) == 0
+    assert cabi.filterinterp_forward_ori_f16(gfr[1].half(), p2, gk[1], o2) == 0
+    blend16 = (o0.float() * (1.0 - t) + o2.float() * t).half().float()
+    u16 = fused.padded_to_frames(blend16.contiguous(), h, w, (left, right, top, bottom))
+    torch.cuda.synchronize()
+    psnr16 = chain.psnr_u8(cpu(u16), ref["u8"])
+    print("chain parity (%s), fp16 storage: PSNR %.2f dB" % (model, psnr16))
+    assert psnr16 >= 45.0

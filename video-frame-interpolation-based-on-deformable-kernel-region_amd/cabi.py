@@ -36,6 +36,8 @@ SIGNATURES = {
     "vfi_filterinterp_backward_defor": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides,
                                         Strides, Strides, _p],
     "vfi_flowprojection_forward": [_p, _p, _p, _i, _i, _i, _i, Strides, Strides, _p],
+    "vfi_flowprojection_forward_batch": [_p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, _p],
+    "vfi_depthflowprojection_forward_batch": [_p, _p, _p, _p, _i, _i, _i, _i, _i, Strides, Strides, Strides, _p],
     "vfi_flowprojection_backward": [_p, _p, _p, _p, _i, _i, _i, Strides, Strides, _p],
     "vfi_projection_reserve": [_i, _i, _i, _p],
     "vfi_release_workspaces": [],
@@ -258,6 +260,39 @@ def flowprojection_forward(input1, count, output, fillhole):
     with torch.cuda.device(_dev(input1)):
         return _finish(lib().vfi_flowprojection_forward(_ptr(input1), _ptr(count), _ptr(output), b, h, w,
                                                         int(fillhole), _st(input1), _st(count), _stream(input1)))
+
+
+def flowprojection_forward_batch(inputs1, counts, outputs, fillhole, inputs2=None):
+    """The list form of flowprojection_forward / depthflowprojection_forward (inputs2: one depth tensor per item, or one
+    tensor shared by all): every item in one launch triple.  Items share shape and strides."""
+    n = len(inputs1)
+    if n == 0 or len(counts) != n or len(outputs) != n:
+        return 1
+    if inputs2 is not None and not isinstance(inputs2, (list, tuple)):
+        inputs2 = [inputs2] * n
+    if inputs2 is not None and len(inputs2) != n:
+        return 1
+    f0, c0 = inputs1[0], counts[0]
+    b, _, h, w = f0.shape
+    for i in range(n):
+        fl, cn, out = inputs1[i], counts[i], outputs[i]
+        if fl.size(1) != 2 or tuple(fl.shape) != tuple(f0.shape) or tuple(out.shape) != tuple(f0.shape) or tuple(cn.shape) != (b, 1, h, w):
+            return 1
+        if not _same_strides(fl, f0) or not _same_strides(out, f0) or not _same_strides(cn, c0):
+            return 1
+        _dev(fl), _dev(cn), _dev(out)
+        if inputs2 is not None:
+            d = inputs2[i]
+            if tuple(d.shape) != (b, 1, h, w) or not _same_strides(d, inputs2[0]):
+                return 1
+            _dev(d)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])     # noqa: E731
+    with torch.cuda.device(_dev(f0)):
+        if inputs2 is None:
+            return _finish(lib().vfi_flowprojection_forward_batch(arr(inputs1), arr(counts), arr(outputs), n, b, h, w, int(fillhole),
+                                                                  _st(f0), _st(c0), _stream(f0)))
+        return _finish(lib().vfi_depthflowprojection_forward_batch(arr(inputs1), arr(inputs2), arr(counts), arr(outputs), n, b, h, w,
+                                                                   int(fillhole), _st(f0), _st(inputs2[0]), _st(c0), _stream(f0)))
 
 
 def projection_reserve(batch, h, w, device=None):

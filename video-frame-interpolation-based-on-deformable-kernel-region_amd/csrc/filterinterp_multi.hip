@@ -13,6 +13,16 @@
 //
 // Tiling, LDS-DMA ring, counted vmcnt and tile -> XCD grouping: exactly filterinterp_lds.hip (see there); a thread
 // owns two pixels, each with NT (validity, window address, blend weights) and one set of 16 filter taps.
+//
+// Round 4: the window is staged as PAIRS.  With NT outputs per staged window the launch is bound by its consumer side --
+// LDS tap reads and vector issue (profiles/: three times the single-flow kernel's LDS cycles for one window's staging) --
+// not by memory.  A tap row of the single-flow kernel is two ds_read2_b32 (columns (0, 2) and (1, 3), so that one packed
+// multiply-add advances the left and the right quadrant sum): 128 B/clk.  Here the slot holds P[r][c] = (A[r][c], A[r][c + 2])
+// as one 8-byte element, so the same two register pairs are two ds_read_b64 at P[c], P[c + 1] -- 8-byte aligned for every
+// c, 256 B/clk, 64 banks (a stretching flow has slack).  The LDS-DMA writes consecutive dwords, so lane 2i of a staging
+// instruction fetches column i and lane 2i + 1 column i + 2: every window element is staged twice (from L2 the second
+// time), which the NT outputs per window pay for.  The four blend weights of an evaluation are formed once per tile
+// (blend4's own products: same bits) instead of once per channel.
 #include "filterinterp_dev.h"
 
 #include <limits.h>
@@ -27,9 +37,10 @@ namespace vfi {
 #define FM_THREADS (FM_TW * FM_TH / FM_PX)          // 512
 #define FM_PASS_ROWS (FM_TH / FM_PX)
 #define FM_HDR 16
-#define FM_RING_FLOATS 15984                        // with the header: 64,000 B
+#define FM_RING_FLOATS 20464                        // with the header: 81,920 B = half of a CU's 160 KB (two workgroups per CU)
 #define FM_RMAX 5
-#define FM_KTOP 15
+#define FM_KTOP 15                                  // staged dwords per thread and channel, at most
+#define FM_KPAIR 13                                 // ... of a window staged as pairs (three ring slots)
 #define FM_XCDS 8
 #define FM_MAXT 3                                   // flows per launch (4 spills inside the channel loop at 128 registers)
 
@@ -45,14 +56,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct FmPtrs { const float* flow[FM_MAXT]; float* out[FM_MAXT]; };
-struct FmWindow { int bx0, by0, bw, bh, pitch, h, w, hs; };
+struct FmWindow { int bx0, by0, bwp, bh, pitch, h, w, hs; };    // bwp / pitch: staged columns (pairs: bw - 2) and row pitch, in pairs / dwords
 template <int NT> struct FmPixel {
     bool inimg;
     unsigned pix;           // element offset of the pixel inside an image plane
     float f[16];
     bool valid[NT];
     float alpha[NT], beta[NT];
-    int lbase[NT];          // LDS index of the 4x4 window origin of flow t inside the staged window
+    int lbase[NT];          // pair index of the 4x4 window origin of flow t inside the staged window
 };
 
 template <int K>
@@ -66,13 +77,163 @@ __device__ __forceinline__ void fm_wait_windows(int younger_groups) {
 }
 
 // Channel loop of one workgroup, written like fi_run_channels_lean (filterinterp_lds.hip: what bounds these loops is the
-// instruction count): ring geometry a compile-time function of K and one constant s_waitcnt in the steady state, running
+// instruction count and the LDS cycles): ring geometry a compile-time function of K and one constant s_waitcnt in the steady
+// state, running plane pointers, M0 formed on the scalar unit, tap reads as asm (8-byte pairs, see the head of the file) with
+// one lgkmcnt wait per evaluation and the next evaluation's first rows in flight under the current one's arithmetic,
+// range-checked buffer stores.  An evaluation = one pixel under one flow: 2 x NT per thread and channel, each 8 LDS reads,
+// 8 packed multiply-adds and the 4 operations of the blend.
+template <int K, int NT>
+__device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
+                                                int c_begin, int c_end, int tid, const FmWindow& win,
+                                                const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr int NP = K * FM_THREADS;                      // dwords per ring slot
+    constexpr int R = (FM_RING_FLOATS / NP) < FM_RMAX ? (FM_RING_FLOATS / NP) : FM_RMAX;
+    constexpr int D = R - 1;
+    constexpr int NE = FM_PX * NT;                           // evaluations per thread and channel, e = t * FM_PX + p
+    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    if (c_begin >= c_end) return;
+    // staged dword e = tid + k * FM_THREADS = half (e & 1) of pair e >> 1; pairs row-major with a pitch that is a multiple of
+    // 32 pairs (the 64 banks an 8-byte read sees: a tap's bank depends on its column only); borders replicated while staging,
+    // pad pairs out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
+    const float inv_pitch = 1.0f / (float)win.pitch;
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + k * FM_THREADS;
+        const int pe = e >> 1, half = e & 1;
+        const int r = fi_row_of(pe, inv_pitch);
+        const int colp = pe - r * win.pitch;
+        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + colp + 2 * half, 0, win.w - 1));
+        goff[k] = (colp < win.bwp && r < win.bh) ? off : 0x80000000u;
+    }
+    const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(fm_lptr_t)ring;
+    const unsigned pitch8 = 8u * (unsigned)win.pitch;
+    unsigned lb[NE], pix4[FM_PX];
+    float W[NE][4];                                          // blend4's weights of an evaluation: (1-a)(1-b), a(1-b), (1-a)b, ab
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < FM_PX; ++p) {
+            const int e = t * FM_PX + p;
+            lb[e] = ring_lds + 8u * (unsigned)px[p].lbase[t];                   // (an invalid evaluation's reads land anywhere: discarded)
+            pix4[p] = 4u * px[p].pix;
+            const float al = px[p].alpha[t], be = px[p].beta[t];
+            W[e][0] = (1.0f - al) * (1.0f - be); W[e][1] = al * (1.0f - be); W[e][2] = (1.0f - al) * be; W[e][3] = al * be;
+        }
+    // filter taps as (left quadrant, right quadrant) pairs: rows 0-1 feed the top sums, rows 2-3 the bottom ones
+    v2f F[FM_PX][8];
+#pragma unroll
+    for (int p = 0; p < FM_PX; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            F[p][2 * r] = v2f{px[p].f[4 * r], px[p].f[4 * r + 2]};
+            F[p][2 * r + 1] = v2f{px[p].f[4 * r + 1], px[p].f[4 * r + 3]};
+        }
+    const int last = c_end - 1;
+    const float* pdma = img + (int64_t)c_begin * cs;
+    int64_t oofs = boff + (int64_t)c_begin * cs;            // element offset of the output plane inside every output tensor
+    auto issue = [&](int slot) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
+        float* l = ring + slot * NP + wave_first;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fm_lptr_t)(l + k * FM_THREADS), 4, goff[k], 0, 0, 0);
+        pdma += cs;
+    };
+#define FM_READ64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
+    auto compute = [&](int slot) {
+        const unsigned so = (unsigned)(slot * (NP * 4));
+        // Two register sets of four pairs ping-pong at half-evaluation grain: while the top sums of evaluation e are formed from
+        // rows 0-1 (set 0), rows 2-3 (set 1) are in flight; while the bottom sums are formed, rows 0-1 of evaluation e + 1 are.
+        // (Whole evaluations in flight -- 2 x 8 pairs -- do not fit beside 2 x 3 evaluations' state at 128 registers.)
+        v2f q[2][4];
+        auto reads = [&](auto E, auto H) {                   // rows 2h, 2h + 1 of evaluation e into set h
+            constexpr int e = decltype(E)::value, h = decltype(H)::value;
+            v2f (&d)[4] = q[h];
+            unsigned a = lb[e] + so + (h ? 2u * pitch8 : 0u);
+            FM_READ64(d[0], a, 0); FM_READ64(d[1], a, 8);
+            a += pitch8;
+            FM_READ64(d[2], a, 0); FM_READ64(d[3], a, 8);
+        };
+        auto landed = [&](v2f (&d)[4], auto LATER) {         // all but the `later` youngest LDS reads are back
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(decltype(LATER)::value));
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I4 = std::integral_constant<int, 4>;
+        reads(I0{}, I0{}); reads(I0{}, I1{});
+        static_for<0, NE>([&](auto E) {
+            constexpr int e = decltype(E)::value, t = e / FM_PX, p = e % FM_PX;
+            // d[2r] = columns (0, 2), d[2r + 1] = columns (1, 3) of row r: the sums of fi4_pixel, two quadrants per instruction
+            landed(q[0], I4{});
+            v2f top = q[0][0] * F[p][0];
+            top = __builtin_elementwise_fma(q[0][1], F[p][1], top);
+            top = __builtin_elementwise_fma(q[0][2], F[p][2], top);
+            top = __builtin_elementwise_fma(q[0][3], F[p][3], top);
+            if constexpr (e + 1 < NE) { reads(std::integral_constant<int, e + 1>{}, I0{}); landed(q[1], I4{}); }
+            else landed(q[1], I0{});
+            v2f bot = q[1][0] * F[p][4];
+            bot = __builtin_elementwise_fma(q[1][1], F[p][5], bot);
+            bot = __builtin_elementwise_fma(q[1][2], F[p][6], bot);
+            bot = __builtin_elementwise_fma(q[1][3], F[p][7], bot);
+            if constexpr (e + 1 < NE) reads(std::integral_constant<int, e + 1>{}, I1{});
+            float val = W[e][0] * top.x;                    // (blend4, its weights formed above)
+            val = fmaf(W[e][1], top.y, val);
+            val = fmaf(W[e][2], bot.x, val);
+            val = fmaf(W[e][3], bot.y, val);
+            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
+            // an invalid evaluation's store is dropped by the range check.  (The select is formed here, from a validity mask
+            // the compiler keeps in scalar registers: six loop-invariant offsets instead of two cost the four registers that
+            // spill inside the loop at K >= 10.)
+            unsigned po = pix4[p];
+            asm volatile("" : "+v"(po));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
+        });
+        oofs += cs;
+    };
+#undef FM_READ64
+    const int n0 = min(D, c_end - c_begin);
+    for (int j = 0; j < n0; ++j) issue(j);
+    fm_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
+    __builtin_amdgcn_s_barrier();                               // ... in every wave
+    int c = c_begin, slot = 0;
+    for (; c + D <= last; ++c) {                                // steady state: window c + D exists
+        issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        compute(slot);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
+        compute(slot);
+        if (c < last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    // copy-through of the invalid pixels (:2814-2818), outside the pipelined loop
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < FM_PX; ++p)
+            if (px[p].inimg && !px[p].valid[t])
+                for (int cc = c_begin; cc < c_end; ++cc)
+                    ptr.out[t][boff + (int64_t)cc * cs + px[p].pix] = img[(int64_t)cc * cs + px[p].pix];
+}
+
+// The same loop on a PLAIN window (one dword per element, tap rows as two ds_read2_b32: rounds 2-3) -- for tiles whose window
+// does not fit the ring as pairs (rough flow fields: a window of 98 x 50 elements is 12.5 dwords per thread plain, 25 as
+// pairs).  Written like fi_run_channels_lean (filterinterp_lds.hip): ring geometry a compile-time function of K and one constant s_waitcnt in the steady state, running
 // plane pointers, M0 formed on the scalar unit, tap reads as asm (columns (0, 2) / (1, 3) of a row, so that one packed
 // multiply-add advances the left and the right quadrant sum) with one lgkmcnt wait per evaluation and the next evaluation's
 // first rows in flight under the current one's arithmetic, range-checked buffer stores.  An evaluation = one pixel under
 // one flow: 2 x NT per thread and channel.
 template <int K, int NT>
-__device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
+__device__ __forceinline__ void fm_run_channels_plain(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
                                                 int c_begin, int c_end, int tid, const FmWindow& win,
                                                 const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring) {
     typedef float v2f __attribute__((ext_vector_type(2)));
@@ -92,7 +253,7 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
         const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
-        goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
+        goff[k] = (col < win.bwp && r < win.bh) ? off : 0x80000000u;    // (bwp = the window width here)
     }
     const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
     const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
@@ -222,7 +383,7 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
 template <int NT>
 __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
     const float* __restrict__ in1, FmPtrs ptr, const float* __restrict__ in3, int channel, int h, int w,
-    vfi_strides s1, vfi_strides s2, vfi_strides s3, int tiles_x, int tiles_y, int ntiles, int ch_per_group) {
+    vfi_strides s1, vfi_strides s2, vfi_strides s3, int tiles_x, int tiles_y, int ntiles, int ch_per_group, int kpair) {
     __shared__ float lds[FM_HDR + FM_RING_FLOATS];
     int* box = reinterpret_cast<int*>(lds);
 
@@ -307,8 +468,13 @@ __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
     const bool any_valid = bx0 != INT_MAX;
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
     const int bh = any_valid ? box[3] - by0 + 1 : 0;
-    const int pitch = (bw + 31) & ~31;
-    const int n = pitch * bh;
+    // the slot holds pairs (column c, column c + 2): bw - 2 of them per row, pitch a multiple of 32 pairs; a window too large
+    // for that is staged plain (pitch a multiple of 32 dwords)
+    const int bwp = any_valid ? bw - 2 : 0;
+    const int pitch_pairs = (bwp + 31) & ~31;
+    const bool paired = (2 * pitch_pairs * bh + FM_THREADS - 1) / FM_THREADS <= kpair;      // (kpair <= FM_KPAIR)
+    const int pitch = paired ? pitch_pairs : (bw + 31) & ~31;
+    const int n = paired ? 2 * pitch * bh : pitch * bh;     // dwords
 #pragma unroll
     for (int p = 0; p < FM_PX; ++p)
 #pragma unroll
@@ -334,19 +500,26 @@ __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
         return;
     }
 
-    const FmWindow win{bx0, by0, bw, bh, pitch, h, w, (int)s1.h};
+    const FmWindow win{bx0, by0, paired ? bwp : bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FM_HDR;
 #define FM_RUN(K) fm_run_channels<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
-    if (kmax <= 2) FM_RUN(2);
-    else if (kmax == 3) FM_RUN(3);
-    else if (kmax == 4) FM_RUN(4);
-    else if (kmax == 5) FM_RUN(5);
-    else if (kmax == 6) FM_RUN(6);
-    else if (kmax == 7) FM_RUN(7);
-    else if (kmax == 8) FM_RUN(8);
-    else if (kmax <= 10) FM_RUN(10);
-    else if (kmax <= 12) FM_RUN(12);
-    else FM_RUN(15);
+#define FM_RUN_PLAIN(K) fm_run_channels_plain<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
+    // (a whole 64 x 16 tile needs at least 67 x 19 elements = 96 x 19 pairs: K >= 8)
+    if (paired) {
+        if (kmax <= 6) FM_RUN(6);
+        else if (kmax <= 8) FM_RUN(8);
+        else if (kmax == 9) FM_RUN(9);
+        else if (kmax == 10) FM_RUN(10);
+        else if (kmax == 11) FM_RUN(11);
+        else if (kmax == 12) FM_RUN(12);
+        else FM_RUN(13);
+    } else {
+        if (kmax <= 8) FM_RUN_PLAIN(8);
+        else if (kmax <= 10) FM_RUN_PLAIN(10);
+        else if (kmax <= 12) FM_RUN_PLAIN(12);
+        else FM_RUN_PLAIN(15);
+    }
+#undef FM_RUN_PLAIN
 #undef FM_RUN
 }
 
@@ -358,6 +531,12 @@ extern "C" int vfi_filterinterp_forward_ori(const float* input1, const float* in
                                              float* output, int batch, int channel, int h, int w,
                                              int filter_channels, vfi_strides s1, vfi_strides s2, vfi_strides s3,
                                              vfi_stream_t stream);
+
+// largest staged dwords per thread a window may need as pairs (development builds: 0 = every window plain)
+VFI_KNOB(int, g_fm_kpair, FM_KPAIR);
+#ifdef VFI_DEV
+extern "C" void vfi_dev_multi(int kpair) { g_fm_kpair = kpair < FM_KPAIR ? kpair : FM_KPAIR; }
+#endif
 
 extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const float* const* flows, const float* input3,
                                                    float* const* outputs, int nflows, int batch, int channel, int h, int w,
@@ -405,8 +584,8 @@ extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const flo
     const dim3 grid((unsigned)(per_xcd * FM_XCDS), (unsigned)groups, 1), block(FM_THREADS, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     switch (nflows) {
-    case 2: hipLaunchKernelGGL(fi_forward_ori_multi<2>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group); break;
-    default: hipLaunchKernelGGL(fi_forward_ori_multi<3>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group); break;
+    case 2: hipLaunchKernelGGL(fi_forward_ori_multi<2>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
+    default: hipLaunchKernelGGL(fi_forward_ori_multi<3>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
     }
     return launch_status();
 }

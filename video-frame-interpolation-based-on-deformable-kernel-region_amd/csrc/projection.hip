@@ -103,12 +103,28 @@ struct ProjGeom {
 // (The network's quarter-resolution flow goes through flow_upsample4 first: vfi_*_forward_up4 below.)
 // Row strides are 32-bit here (the host checks that every in-plane offset fits): the kernels address a
 // plane as uniform base + 32-bit offset.
+// A call projects a LIST of flows (the networks' FlowProject(inputs, depth): networks/DAIN.py:533-539,
+// networks/DAIN_slowmotion.py:301-307 -- one launch triple for the whole list instead of one per flow): item i < n has its own
+// flow / depth / count / output tensors, all items share shape and strides.  The kernels see n * per "images"; image b is
+// image b % per of item b / per.  (The pointer tables are kernel arguments, by value: a captured graph replays them.)
+#define PROJ_NMAX 8
 struct ProjSrc {
-    const float* flow;      // [B,2,h,w]
-    const float* depth;     // [B,1,h,w] (DEPTH only)
+    const float* flow[PROJ_NMAX];       // [per,2,h,w] each
+    const float* depth[PROJ_NMAX];      // [per,1,h,w] each (DEPTH only; items may share one)
     int64_t fb, fc, db;     // flow batch / channel stride, depth batch stride
     int fh, dh;             // row strides
+    int per;                // images per item
 };
+struct ProjDst {
+    float* count[PROJ_NMAX];            // [per,1,h,w] each
+    float* out[PROJ_NMAX];              // [per,2,h,w] each
+};
+struct ProjImage { int item, bi; };
+__device__ __forceinline__ ProjImage proj_image(int b, int per) {
+    if (per == 1) return ProjImage{b, 0};
+    const int it = b / per;
+    return ProjImage{it, b - it * per};
+}
 
 // torch's upsample_bilinear2d, align_corners=False, scale factor 4 (ATen UpSampleBilinear2d):
 // source index 0.25 * (dst + 0.5) - 0.5 clamped at 0, second tap one further unless at the edge
@@ -147,13 +163,14 @@ struct ProjPlanes { __amdgpu_buffer_rsrc_t f0, f1, d; };
 
 template <bool DEPTH>
 __device__ __forceinline__ ProjPlanes proj_planes(const ProjSrc& s, int b, int h, int w) {
-    const float* f0 = s.flow + (int64_t)b * s.fb;
+    const ProjImage im = proj_image(b, s.per);
+    const float* f0 = s.flow[im.item] + (int64_t)im.bi * s.fb;
     ProjPlanes p;
     p.f0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, 0, ((h - 1) * s.fh + w) * 4, 0x00020000);
     p.f1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f0 + s.fc), 0, ((h - 1) * s.fh + w) * 4, 0x00020000);
     p.d = p.f0;
     if constexpr (DEPTH)
-        p.d = __builtin_amdgcn_make_buffer_rsrc((void*)(s.depth + (int64_t)b * s.db), 0, ((h - 1) * s.dh + w) * 4, 0x00020000);
+        p.d = __builtin_amdgcn_make_buffer_rsrc((void*)(s.depth[im.item] + (int64_t)im.bi * s.db), 0, ((h - 1) * s.dh + w) * 4, 0x00020000);
     return p;
 }
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -596,7 +613,7 @@ __device__ __forceinline__ void pull_add(unsigned long long* accv, typename Proj
 // VEC: the flow (and depth) rows are 16-byte aligned, so a lane can load four pixels at once
 template <bool DEPTH, bool VEC>
 __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
-    ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
+    ProjSrc src, ProjDst dst, ProjGeom g, int64_t ob, int64_t oc, int oh,
     int64_t cb, int ch, int vec_ok, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats) {
     typedef typename ProjCountCell<DEPTH>::type ccell;
     __shared__ uint4 lds[ProjLds<DEPTH>::total / 16];
@@ -838,9 +855,12 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     // normalise (flowprojection_cuda_kernel.cu:129-134) and write the tile once, 16 bytes per lane; leave the two
     // "count != 0" bitmaps for the hole filler and put the tile on its list if it has holes
     int holes = 0, negs = 0;
-    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)(count + (int64_t)b * cb), 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
+    const ProjImage im = proj_image(b, src.per);
+    float* const out = dst.out[im.item] + (int64_t)im.bi * ob;
+    float* const count = dst.count[im.item] + (int64_t)im.bi * cb;
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)count, 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
 #pragma unroll
     for (int it = 0; it < PROJ_EPI_ITERS; ++it) {
         const int yl = it * 4 * PROJ_NW + wave * 4 + rw, y = oy0 + yl;
@@ -971,7 +991,7 @@ __device__ __forceinline__ float pl_rcp(float d) {
 
 template <bool DEPTH>
 __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
-    ProjSrc src, float* __restrict__ count, float* __restrict__ out, ProjGeom g, int64_t ob, int64_t oc, int oh,
+    ProjSrc src, ProjDst dst, ProjGeom g, int64_t ob, int64_t oc, int oh,
     int64_t cb, int ch, int* __restrict__ ws, int* __restrict__ bits, float* __restrict__ planes, int64_t plane_floats) {
     typedef PlLds<DEPTH> LY;
     constexpr int P = LY::P, PC = LY::PC;
@@ -1043,9 +1063,12 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
     const int q = lane & 15, rw = lane >> 4;
     const int xq = ox0 + 4 * q;
     const bool edge_x = ox0 + PROJ_TW >= g.w, edge_y = oy0 + PROJ_TH >= g.h;     // the tile touches the frame's last column / row
-    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (int64_t)b * ob + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)(count + (int64_t)b * cb), 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
+    const ProjImage im = proj_image(b, src.per);
+    float* const out = dst.out[im.item] + (int64_t)im.bi * ob;
+    float* const count = dst.count[im.item] + (int64_t)im.bi * cb;
+    const __amdgpu_buffer_rsrc_t ro0 = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc((void*)(out + oc), 0, ((g.h - 1) * oh + g.w) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcn = __builtin_amdgcn_make_buffer_rsrc((void*)count, 0, ((g.h - 1) * ch + g.w) * 4, 0x00020000);
 
     // the 2x2 sums of one pass for the lane's four cells: lo / hi halves of the value cells; count cells: clo = weight sum
     // (depth), chi = addends
@@ -1351,7 +1374,7 @@ __device__ __forceinline__ int mask_next(const unsigned long long* m, int j) {
 // issued for the wave's four rows together.  (Round 2: 1024 threads, a wave per row, the whole column line per lane:
 // 11.4 us per call at 1080p, of which ~5 are the launch and the wait for K1's writes.)
 __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
-    float* __restrict__ count, float* out, ProjGeom g, vfi_strides s1, vfi_strides sc,
+    ProjDst dst, int per, ProjGeom g, vfi_strides s1, vfi_strides sc,
     int* __restrict__ ws, const int* __restrict__ bits, const float* __restrict__ planes, int fillhole) {
     const int tile = band_item(blockIdx.x, gridDim.x);
     // header words [2], [3] (the fallback's dirty extent) and the tile's word from K1 (0 = no holes, 1 = holes, 3 = holes
@@ -1374,7 +1397,9 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
     const int trem = tile - b * per_img;
     const int tyi = trem / g.tiles_x, txi = trem - tyi * g.tiles_x;
     const int x = txi * PROJ_TW + lane, y0 = tyi * PROJ_TH + wave * PROJ_FIN_ROWS;
-    float* o0 = out + (int64_t)b * s1.b;
+    const ProjImage im = proj_image(b, per);
+    float* const count = dst.count[im.item] + (int64_t)im.bi * sc.b;
+    float* o0 = dst.out[im.item] + (int64_t)im.bi * s1.b;
     float* o1 = o0 + s1.c;
     if (fallback) {
         // K1 left sums in the scratch planes: normalise (pass 2) and fill holes (pass 3) from them
@@ -1389,7 +1414,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
             const int64_t row = (int64_t)y * s1.h;
             const int64_t me = (int64_t)y * g.w + x;
             const float c = pc[me];
-            count[(int64_t)b * sc.b + (int64_t)y * sc.h + x] = c;
+            count[(int64_t)y * sc.h + x] = c;
             if (c > 0.0f) {
                 o0[row + x] = p0[me] / c;
                 o1[row + x] = p1[me] / c;
@@ -1419,7 +1444,7 @@ __global__ __launch_bounds__(PROJ_FIN_THREADS) void proj_finish(
         }
         return;
     }
-    const float* cn = count + (int64_t)b * sc.b;
+    const float* cn = count;
     const int xc = min(x, g.w - 1);
     const int* cl = bits + g.colmap + (b * g.w + xc) * g.cmw;
     int xl[PROJ_FIN_ROWS], xr[PROJ_FIN_ROWS], yu[PROJ_FIN_ROWS], yd[PROJ_FIN_ROWS];
@@ -1610,27 +1635,44 @@ static bool proj_buffers(hipStream_t st, const ProjSizes& z, ProjBuffers* p) {
 // every in-plane element offset of a [*, *, h, w] tensor with row stride sh fits 31 bits
 static bool fits32(int64_t sh, int h, int w) { return sh >= 0 && sh * (int64_t)(h - 1) + w < ((int64_t)1 << 31); }
 
-// sf = strides of the flow, s1 = strides of `out` (the reference binding shares them)
+// The launch triple for n <= PROJ_NMAX items of `per` images each.  sf = strides of the flows, s1 = strides of the outputs
+// (the reference binding shares them), s2 / sc = strides of the depths / counts.
 template <bool DEPTH>
-static int project_forward(const float* flow, vfi_strides sf, const float* in2, float* count, float* out, int batch, int h, int w,
-                           int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
+static int project_forward_list(const float* const* flows, vfi_strides sf, const float* const* depths, float* const* counts,
+                                float* const* outs, int n, int per, int h, int w, int fillhole, vfi_strides s1, vfi_strides s2,
+                                vfi_strides sc, hipStream_t st) {
+    if (n <= 0 || n > PROJ_NMAX || per <= 0 || (int64_t)n * per > INT_MAX) return VFI_ERR_SHAPE;
+    const int images = n * per;
     ProjGeom g;
     ProjSizes z;
-    if (!proj_geometry(batch, h, w, &g, &z)) return VFI_ERR_SHAPE;
+    if (!proj_geometry(images, h, w, &g, &z)) return VFI_ERR_SHAPE;
     if (!fits32(sf.h, h, w) || !fits32(s1.h, h, w) || !fits32(sc.h, h, w) || (DEPTH && !fits32(s2.h, h, w)))
         return VFI_ERR_SHAPE;
     ProjBuffers p;
     if (!proj_buffers(st, z, &p)) return VFI_ERR_LAUNCH;
     ProjSrc src;
-    src.flow = flow; src.depth = in2;
+    ProjDst dst;
+    // 16-byte lanes need 16-byte aligned rows
+    bool vec_in = sf.b % 4 == 0 && sf.c % 4 == 0 && sf.h % 4 == 0 && (!DEPTH || (s2.b % 4 == 0 && s2.h % 4 == 0));
+    bool vec_out = s1.b % 4 == 0 && s1.c % 4 == 0 && s1.h % 4 == 0 && sc.b % 4 == 0 && sc.h % 4 == 0;
+    for (int i = 0; i < PROJ_NMAX; ++i) {
+        const int k = i < n ? i : 0;                        // (unused slots repeat item 0)
+        if (!flows[k] || !counts[k] || !outs[k] || (DEPTH && !depths[k])) return VFI_ERR_SHAPE;
+        src.flow[i] = flows[k]; src.depth[i] = DEPTH ? depths[k] : nullptr;
+        dst.count[i] = counts[k]; dst.out[i] = outs[k];
+        vec_in = vec_in && (uintptr_t)flows[k] % 16 == 0 && (!DEPTH || (uintptr_t)depths[k] % 16 == 0);
+        vec_out = vec_out && (uintptr_t)outs[k] % 16 == 0 && (uintptr_t)counts[k] % 16 == 0;
+    }
+    // every item's count and output are written in the same launch: they must not share memory
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (counts[i] == counts[j] || outs[i] == outs[j]) return VFI_ERR_SHAPE;
     src.fb = sf.b; src.fc = sf.c; src.db = DEPTH ? s2.b : 0;
     src.fh = (int)sf.h; src.dh = DEPTH ? (int)s2.h : 0;
-    // 16-byte lanes need 16-byte aligned rows
-    const bool vec_in = (uintptr_t)flow % 16 == 0 && sf.b % 4 == 0 && sf.c % 4 == 0 && sf.h % 4 == 0 &&
-                        (!DEPTH || ((uintptr_t)in2 % 16 == 0 && s2.b % 4 == 0 && s2.h % 4 == 0));
+    src.per = per;
     if (vec_in) {
         const int groups_x = (g.tiles_x + 3) / 4;
-        hipLaunchKernelGGL((proj_scan4<DEPTH>), dim3(batch * g.tiles_y * groups_x), dim3(256), 0, st, src, g, groups_x,
+        hipLaunchKernelGGL((proj_scan4<DEPTH>), dim3(images * g.tiles_y * groups_x), dim3(256), 0, st, src, g, groups_x,
                            p.words, p.planes, (int64_t)z.plane_floats);
     } else {
         hipLaunchKernelGGL((proj_scan<DEPTH>), dim3(g.ntiles), dim3(64), 0, st, src, g, p.words, p.planes,
@@ -1638,26 +1680,47 @@ static int project_forward(const float* flow, vfi_strides sf, const float* in2, 
     }
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // 16-byte stores need 16-byte aligned rows
-    const int vec_ok = ((uintptr_t)out % 16 == 0 && (uintptr_t)count % 16 == 0 && s1.b % 4 == 0 && s1.c % 4 == 0 && s1.h % 4 == 0 &&
-                        sc.b % 4 == 0 && sc.h % 4 == 0) ? 1 : 0;
+    const int vec_ok = vec_out ? 1 : 0;
 #ifndef PROJ_NO_LEAN
-    if (vec_in && vec_ok && g.tiles_y <= 65535 && batch <= 65535)
-        hipLaunchKernelGGL((proj_pull_lean<DEPTH>), PROJ_BANDS ? dim3(g.ntiles) : dim3(g.tiles_x, g.tiles_y, batch), dim3(PL_THREADS), 0, st, src, count, out, g,
+    if (vec_in && vec_ok && g.tiles_y <= 65535 && images <= 65535)
+        hipLaunchKernelGGL((proj_pull_lean<DEPTH>), PROJ_BANDS ? dim3(g.ntiles) : dim3(g.tiles_x, g.tiles_y, images), dim3(PL_THREADS), 0, st, src, dst, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     else
 #endif
     if (vec_in)
-        hipLaunchKernelGGL((proj_pull<DEPTH, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+        hipLaunchKernelGGL((proj_pull<DEPTH, true>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, dst, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     else
-        hipLaunchKernelGGL((proj_pull<DEPTH, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, count, out, g,
+        hipLaunchKernelGGL((proj_pull<DEPTH, false>), dim3(g.ntiles), dim3(PROJ_PULL_THREADS), 0, st, src, dst, g,
                            (int64_t)s1.b, (int64_t)s1.c, (int)s1.h, (int64_t)sc.b, (int)sc.h, vec_ok, p.words, p.bits, p.planes, (int64_t)z.plane_floats);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     // (also runs with fillhole == 0: it resets the call's state, and the fallback path normalises there)
-    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_FIN_THREADS), 0, st, count, out, g,
+    hipLaunchKernelGGL(proj_finish, dim3(g.ntiles), dim3(PROJ_FIN_THREADS), 0, st, dst, per, g,
                        s1, sc, p.words, p.bits, p.planes, fillhole);
     if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
     return VFI_OK;
+}
+
+// any number of items: groups of PROJ_NMAX, one launch triple each
+template <bool DEPTH>
+static int project_forward_items(const float* const* flows, vfi_strides sf, const float* const* depths, float* const* counts,
+                                 float* const* outs, int n, int per, int h, int w, int fillhole, vfi_strides s1, vfi_strides s2,
+                                 vfi_strides sc, hipStream_t st) {
+    if (n <= 0 || !flows || !counts || !outs || (DEPTH && !depths)) return VFI_ERR_SHAPE;
+    for (int i0 = 0; i0 < n; i0 += PROJ_NMAX) {
+        const int m = n - i0 < PROJ_NMAX ? n - i0 : PROJ_NMAX;
+        const int err = project_forward_list<DEPTH>(flows + i0, sf, DEPTH ? depths + i0 : nullptr, counts + i0, outs + i0, m, per, h, w,
+                                                    fillhole, s1, s2, sc, st);
+        if (err != VFI_OK) return err;
+    }
+    return VFI_OK;
+}
+
+// the reference bindings' call: one flow tensor
+template <bool DEPTH>
+static int project_forward(const float* flow, vfi_strides sf, const float* in2, float* count, float* out, int batch, int h, int w,
+                           int fillhole, vfi_strides s1, vfi_strides s2, vfi_strides sc, hipStream_t st) {
+    return project_forward_list<DEPTH>(&flow, sf, &in2, &count, &out, 1, batch, h, w, fillhole, s1, s2, sc, st);
 }
 
 // standalone x4 upsample of (m0 * in) * m1 -- forward_flownets as one launch
@@ -1712,6 +1775,22 @@ extern "C" int vfi_depthflowprojection_forward(const float* input1, const float*
                                                 vfi_strides sc, vfi_stream_t stream) {
     if (batch <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !count || !output) return VFI_ERR_SHAPE;
     return project_forward<true>(input1, s1, input2, count, output, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
+}
+
+// FlowProject(inputs, depth) of the networks: every flow of the list (and, when the caller concatenates them, of both directions)
+// in one launch triple per PROJ_NMAX items
+extern "C" int vfi_flowprojection_forward_batch(const float* const* inputs1, float* const* counts, float* const* outputs, int nitems,
+                                                 int batch, int h, int w, int fillhole, vfi_strides s1, vfi_strides sc,
+                                                 vfi_stream_t stream) {
+    if (nitems <= 0 || batch <= 0 || h <= 0 || w <= 0 || !inputs1 || !counts || !outputs) return VFI_ERR_SHAPE;
+    return project_forward_items<false>(inputs1, s1, nullptr, counts, outputs, nitems, batch, h, w, fillhole, s1, s1, sc, (hipStream_t)stream);
+}
+
+extern "C" int vfi_depthflowprojection_forward_batch(const float* const* inputs1, const float* const* inputs2, float* const* counts,
+                                                      float* const* outputs, int nitems, int batch, int h, int w, int fillhole,
+                                                      vfi_strides s1, vfi_strides s2, vfi_strides sc, vfi_stream_t stream) {
+    if (nitems <= 0 || batch <= 0 || h <= 0 || w <= 0 || !inputs1 || !inputs2 || !counts || !outputs) return VFI_ERR_SHAPE;
+    return project_forward_items<true>(inputs1, s1, inputs2, counts, outputs, nitems, batch, h, w, fillhole, s1, s2, sc, (hipStream_t)stream);
 }
 
 // ---- fused glue: forward_flownets + FlowProject (networks/DAIN_slowmotion.py:204-216, 301-308)

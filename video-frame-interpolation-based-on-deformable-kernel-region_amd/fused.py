@@ -61,6 +61,29 @@ def forward_flownets_upsample(flow_q, div_flow, time_offsets):
     return outs
 
 
+def FlowProject(inputs, depth=None, fillhole=True):
+    """`DAIN.FlowProject` / `DAIN_slowmotion.FlowProject` (networks/DAIN.py:533-539, networks/DAIN_slowmotion.py:301-307):
+    inputs = the list of full-resolution flows of `forward_flownets`, depth = the direction's inverse depth (or None);
+    returns the list of projected flows.  The reference loops over the list, one module call per flow; here the list is
+    ONE call of the library (one launch triple per eight flows), same results bit for bit.  depth may also be a list, one
+    tensor per flow -- which is how both directions go through together: `FlowProject_directions`."""
+    inputs = list(inputs)
+    counts = [torch.empty((f.size(0), 1, f.size(2), f.size(3)), device=f.device, dtype=torch.float32) for f in inputs]
+    outs = [torch.empty_strided(f.shape, f.stride(), device=f.device, dtype=torch.float32) for f in inputs]
+    _check(cabi.flowprojection_forward_batch(inputs, counts, outs, int(fillhole), depth), "flowprojection_forward_batch")
+    return outs
+
+
+def FlowProject_directions(cur_offset_outputs, depth_inv=None, fillhole=True):
+    """The two `FlowProject` calls of `forward` back to back (networks/DAIN.py:215-220, networks/DAIN_slowmotion.py:156-159):
+    `[FlowProject(cur_offset_outputs[0], depth_inv[0]), FlowProject(cur_offset_outputs[1], depth_inv[1])]` as one call."""
+    n0 = len(cur_offset_outputs[0])
+    flows = list(cur_offset_outputs[0]) + list(cur_offset_outputs[1])
+    depth = None if depth_inv is None else [depth_inv[0]] * n0 + [depth_inv[1]] * len(cur_offset_outputs[1])
+    outs = FlowProject(flows, depth, fillhole)
+    return [outs[:n0], outs[n0:]]
+
+
 def FlowProject_from_quarter(flow_q, div_flow, time_offsets, depth=None, fillhole=True):
     """`forward_flownets` + `FlowProject` (inference: fillhole) in one call per time offset: the full-resolution flow lives in
     a scratch tensor of the library, not in a tensor of the caller."""
