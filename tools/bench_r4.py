@@ -44,9 +44,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--kpair", type=int, default=None, help="development build: largest K staged as pairs by the shared-window kernel (0 = never)")
+    ap.add_argument("--group", type=int, default=3, help="development build: flows per shared-window launch (2 or 3)")
     args = ap.parse_args()
     if args.kpair is not None:
-        cabi.lib().vfi_dev_multi(args.kpair)
+        cabi.lib().vfi_dev_multi(args.kpair, args.group)
     dev = torch.device("cuda:0")
     h, w = S.padded_size(args.height, args.width)
     px = h * w
@@ -106,6 +107,23 @@ def main():
                 o3 = torch.empty_like(frame)
                 us = timed(lambda i: cabi.filterinterp_forward_ori(frame, projs[1], filt, o3), args.iters)
                 print("fi3      %-8s %8.1f us, %6.1f GB/s algorithmic" % (model, us, 96.0 * px / us / 1e3), flush=True)
+            if "sched" in what:
+                # both directions' context warps (three time offsets each) on two streams, as the best schedule runs them
+                from vfidkr_amd import fused
+                lanes = fused.DirectionStreams(dev)
+                ctx2 = S.context(1, 196, h, w, gen).to(dev)
+                outs2 = [torch.empty_like(ctx2) for _ in range(3)]
+
+                def both(i):
+                    lanes.fork()
+                    with lanes.direction(0):
+                        assert cabi.filterinterp_forward_ori_multi(ctx, projs, filt, outs) == 0
+                    with lanes.direction(1):
+                        assert cabi.filterinterp_forward_ori_multi(ctx2, projs, filt, outs2) == 0
+                    lanes.join()
+                us = timed(both, max(5, args.iters // 5))
+                print("sched    %-8s both directions' context warps (2 x 3 outputs) on two streams: %8.1f us" % (model, us), flush=True)
+                del ctx2, outs2
             del ctx, outs
 
 

@@ -23,7 +23,7 @@ from vfidkr_amd import cabi, synthetic as S  # noqa: E402
 model = sys.argv[1] if len(sys.argv) > 1 else "smooth"
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if kpair is not None:
-    cabi.lib().vfi_dev_multi(kpair)
+    cabi.lib().vfi_dev_multi(kpair, 3)
 dev = torch.device("cuda:0")
 h, w = S.padded_size(1080, 1920)
 gen = S.generator()

@@ -846,9 +846,11 @@ extern "C" int vfi_correlation_forward(const float* input1, const float* input2,
     if (kernel_size == 1 && stride1 == 1 && stride2 == 1 && max_displacement == 4) {
         const int64_t big_tiles = (int64_t)((ow + 31) / 32) * ((oh + 7) / 8) * batch;
         const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
-        // 16-byte staging needs rows, planes and bases aligned (plane = h * w floats)
+        // 16-byte staging needs rows, planes and bases aligned (plane = h * w floats); the tiled kernel writes a lane's two
+        // pixels as one 8-byte store: an output view at an odd element offset of its storage takes the other kernels
         const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
-                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 15) == 0;
+                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 15) == 0 &&
+                             (reinterpret_cast<uintptr_t>(output) & 7) == 0;
         if (small_tiles < g_corr_flat_threshold) {
             const int64_t total = (int64_t)batch * oc * oh * ow;
             hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,

@@ -73,6 +73,11 @@ __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_forward_ori_direct(
 #define FB_THREADS (FB_TW * FB_TH)
 #define FB_CH 3                                     // channels summed per pass
 #define FB_CELLS 6144                               // 64-bit gradient cells per pass (49,152 bytes); half as many bytes of image windows
+// what the launch bound promises must also hold for the LDS array: FB_WAVES waves per SIMD = FB_WAVES * 256 / FB_THREADS
+// workgroups per CU, each with (2 + 1.5 FB_CELLS) * 8 bytes of the CU's 160 KB (a build that overrides FB_TH or FB_WAVES
+// would otherwise keep compiling and silently lose occupancy)
+static_assert(FB_THREADS <= 1024 && FB_THREADS % 64 == 0, "workgroup size");
+static_assert(((FB_WAVES * 256) / FB_THREADS) * (2 + FB_CELLS + FB_CELLS / 2) * 8 <= 160 * 1024, "workgroups per CU x LDS per workgroup exceed the CU's LDS");
 
 __global__ __launch_bounds__(VFI_TX * VFI_TY) void fi_backward_ori(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
@@ -703,7 +708,7 @@ extern "C" int vfi_filterinterp_backward_ori(const float* input1, const float* i
     const int fs = fi_filter_size(filter_channels);
     unsigned long long* acc;
     int* hdr;
-    int* flags = nullptr;                                   // one word per 64x16 tile: "the staged kernel left it alone"
+    int* flags = nullptr;                                   // one word per FB_TW x FB_TH (64 x 8) tile: "the staged kernel left it alone"
     const int ntiles = ((w + FB_TW - 1) / FB_TW) * ((h + FB_TH - 1) / FB_TH) * batch;
     int err = gradacc_begin((hipStream_t)stream, gradoutput, batch, channel, h, w, s1, input3, filter_channels, s3, &acc, &hdr,
                             fs == 4 ? ntiles : 0, &flags);

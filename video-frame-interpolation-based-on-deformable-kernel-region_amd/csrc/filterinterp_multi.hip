@@ -40,9 +40,12 @@ namespace vfi {
 #define FM_RING_FLOATS 20464                        // with the header: 81,920 B = half of a CU's 160 KB (two workgroups per CU)
 #define FM_RMAX 5
 #define FM_KTOP 15                                  // staged dwords per thread and channel, at most
-#define FM_KPAIR 13                                 // ... of a window staged as pairs (three ring slots)
+#define FM_KPAIR 18                                 // ... of a window staged as pairs: classes 3 x 3 ... 3 x 6, 4 x 3, 4 x 4
 #define FM_XCDS 8
 #define FM_MAXT 3                                   // flows per launch (4 spills inside the channel loop at 128 registers)
+#ifndef FM_GROUP
+#define FM_GROUP 3                                  // flows per launch the host forms groups of
+#endif
 
 typedef __attribute__((address_space(3))) void* fm_lptr_t;
 
@@ -56,6 +59,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct FmPtrs { const float* flow[FM_MAXT]; float* out[FM_MAXT]; };
+
+#ifndef FM_ABL
+#define FM_ABL 0            // development: parts of the paired loop switched off (wrong results, timing only): 1 stores, 2 staging, 4 tap reads
+#endif
+#ifdef FM_STAMPS            // development build only: where a channel step's cycles go (tools/fm_stamps.py)
+__device__ unsigned long long g_fm_stamps[8];       // s_memtime ticks: [0] staging issue, [1] compute, [2] vmcnt wait, [3] barrier, [4] steps
+#define FM_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define FM_T(v)
+#endif
 struct FmWindow { int bx0, by0, bwp, bh, pitch, h, w, hs; };    // bwp / pitch: staged columns (pairs: bw - 2) and row pitch, in pairs / dwords
 template <int NT> struct FmPixel {
     bool inimg;
@@ -76,41 +89,43 @@ __device__ __forceinline__ void fm_wait_windows(int younger_groups) {
     }
 }
 
-// Channel loop of one workgroup, written like fi_run_channels_lean (filterinterp_lds.hip: what bounds these loops is the
-// instruction count and the LDS cycles): ring geometry a compile-time function of K and one constant s_waitcnt in the steady
-// state, running plane pointers, M0 formed on the scalar unit, tap reads as asm (8-byte pairs, see the head of the file) with
-// one lgkmcnt wait per evaluation and the next evaluation's first rows in flight under the current one's arithmetic,
-// range-checked buffer stores.  An evaluation = one pixel under one flow: 2 x NT per thread and channel, each 8 LDS reads,
-// 8 packed multiply-adds and the 4 operations of the blend.
-template <int K, int NT>
+// Channel loop of one workgroup on a window staged as pairs, written like fi_run_channels_lean (filterinterp_lds.hip): ring
+// geometry a compile-time function of the window class and one constant s_waitcnt in the steady state, running plane pointers,
+// tap reads as asm (8-byte pairs, see the head of the file) at immediate offsets from one address per evaluation, with one
+// lgkmcnt wait per half evaluation and the next half's rows in flight under the current one's arithmetic, range-checked buffer
+// stores.  An evaluation = one pixel under one flow: 2 x NT per thread and channel, each 8 LDS reads, 8 packed multiply-adds
+// and the 4 operations of the blend.
+// Window class <S, KR>: row pitch = 32 S pairs = S segments of 64 dwords, at most 8 KR rows.  A staging instruction writes one
+// segment (64 consecutive dwords: what an LDS-DMA writes); wave v stages rows v, v + 8, ... whole: its KR x S instructions
+// share S per-lane column offsets (the lane's column inside segment s, clamped to the frame; out of range for pad pairs) and
+// take the row from the scalar offset operand -- S registers of addressing instead of one per staged dword (K = S KR = 9 ...
+// 18), which is what lets a window of 96 x 48 pairs live beside 2 x 3 evaluations' state in 128 registers.  Rows past the
+// window are staged through a descriptor of zero records: no memory traffic, and no address is formed from their offsets.
+template <int S, int KR, int NT>
 __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, const FmPtrs& ptr, int64_t boff, int64_t cs,
                                                 int c_begin, int c_end, int tid, const FmWindow& win,
                                                 const FmPixel<NT> (&px)[FM_PX], float* __restrict__ ring) {
     typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr int K = S * KR;                               // staging instructions per wave and channel
     constexpr int NP = K * FM_THREADS;                      // dwords per ring slot
     constexpr int R = (FM_RING_FLOATS / NP) < FM_RMAX ? (FM_RING_FLOATS / NP) : FM_RMAX;
     constexpr int D = R - 1;
     constexpr int NE = FM_PX * NT;                           // evaluations per thread and channel, e = t * FM_PX + p
+    constexpr int PITCH8 = 256 * S;                          // row pitch in bytes
     static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    static_assert(3 * PITCH8 + 8 < 65536, "tap rows at immediate offsets");
     if (c_begin >= c_end) return;
-    // staged dword e = tid + k * FM_THREADS = half (e & 1) of pair e >> 1; pairs row-major with a pitch that is a multiple of
-    // 32 pairs (the 64 banks an 8-byte read sees: a tap's bank depends on its column only); borders replicated while staging,
-    // pad pairs out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
-    const float inv_pitch = 1.0f / (float)win.pitch;
-    unsigned goff[K];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // lane's dword inside segment s: half (lane & 1) of pair column 32 s + lane / 2
+    unsigned voff[S];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int e = tid + k * FM_THREADS;
-        const int pe = e >> 1, half = e & 1;
-        const int r = fi_row_of(pe, inv_pitch);
-        const int colp = pe - r * win.pitch;
-        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + colp + 2 * half, 0, win.w - 1));
-        goff[k] = (colp < win.bwp && r < win.bh) ? off : 0x80000000u;
+    for (int s_ = 0; s_ < S; ++s_) {
+        const int colp = 32 * s_ + (lane >> 1);
+        voff[s_] = colp < win.bwp ? 4u * (unsigned)clampi(win.bx0 + colp + 2 * (lane & 1), 0, win.w - 1) : 0x80000000u;
     }
     const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
-    const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
     const unsigned ring_lds = (unsigned)(uintptr_t)(fm_lptr_t)ring;
-    const unsigned pitch8 = 8u * (unsigned)win.pitch;
     unsigned lb[NE], pix4[FM_PX];
     float W[NE][4];                                          // blend4's weights of an evaluation: (1-a)(1-b), a(1-b), (1-a)b, ab
 #pragma unroll
@@ -136,27 +151,38 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
     const float* pdma = img + (int64_t)c_begin * cs;
     int64_t oofs = boff + (int64_t)c_begin * cs;            // element offset of the output plane inside every output tensor
     auto issue = [&](int slot) {
-        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
-        float* l = ring + slot * NP + wave_first;
+        float* l = ring + slot * NP + wave * (64 * S);
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fm_lptr_t)(l + k * FM_THREADS), 4, goff[k], 0, 0, 0);
+        for (int k = 0; k < KR; ++k) {
+            const int row = wave + 8 * k;                                       // (scalar)
+            const bool live = row < win.bh;
+            // (a row past the window: zero records -- every offset out of range)
+            const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, live ? plane_bytes : 0, 0x00020000);
+            const int soff = live ? 4 * clampi(win.by0 + row, 0, win.h - 1) * win.hs : 0;
+#pragma unroll
+            for (int s_ = 0; s_ < S; ++s_)
+                if (!(FM_ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fm_lptr_t)(l + (8 * k * S + s_) * 64), 4, voff[s_], soff, 0, 0);
+        }
         pdma += cs;
     };
-#define FM_READ64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
+#define FM_READ_ROW(d0, d1, addr, r) do { \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d0) : "v"(addr), "n"((r) * PITCH8)); \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((r) * PITCH8 + 8)); } while (0)
     auto compute = [&](int slot) {
         const unsigned so = (unsigned)(slot * (NP * 4));
         // Two register sets of four pairs ping-pong at half-evaluation grain: while the top sums of evaluation e are formed from
         // rows 0-1 (set 0), rows 2-3 (set 1) are in flight; while the bottom sums are formed, rows 0-1 of evaluation e + 1 are.
         // (Whole evaluations in flight -- 2 x 8 pairs -- do not fit beside 2 x 3 evaluations' state at 128 registers.)
         v2f q[2][4];
+        unsigned adr[2];
         auto reads = [&](auto E, auto H) {                   // rows 2h, 2h + 1 of evaluation e into set h
             constexpr int e = decltype(E)::value, h = decltype(H)::value;
             v2f (&d)[4] = q[h];
-            unsigned a = lb[e] + so + (h ? 2u * pitch8 : 0u);
-            FM_READ64(d[0], a, 0); FM_READ64(d[1], a, 8);
-            a += pitch8;
-            FM_READ64(d[2], a, 0); FM_READ64(d[3], a, 8);
+            if constexpr (h == 0) adr[e & 1] = lb[e] + so;
+            const unsigned a = adr[e & 1];
+            if (FM_ABL & 4) { d[0] = d[1] = d[2] = d[3] = v2f{__uint_as_float(a), 1.0f}; return; }
+            FM_READ_ROW(d[0], d[1], a, 2 * h);
+            FM_READ_ROW(d[2], d[3], a, 2 * h + 1);
         };
         auto landed = [&](v2f (&d)[4], auto LATER) {         // all but the `later` youngest LDS reads are back
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(decltype(LATER)::value));
@@ -186,27 +212,44 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
             val = fmaf(W[e][3], bot.y, val);
             const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
             // an invalid evaluation's store is dropped by the range check.  (The select is formed here, from a validity mask
-            // the compiler keeps in scalar registers: six loop-invariant offsets instead of two cost the four registers that
-            // spill inside the loop at K >= 10.)
+            // the compiler keeps in scalar registers: six loop-invariant offsets instead of two cost registers that spill.)
             unsigned po = pix4[p];
             asm volatile("" : "+v"(po));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
+            if (!(FM_ABL & 1) || val == 123456.789f)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
         });
         oofs += cs;
     };
-#undef FM_READ64
+#undef FM_READ_ROW
     const int n0 = min(D, c_end - c_begin);
     for (int j = 0; j < n0; ++j) issue(j);
     fm_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
     int c = c_begin, slot = 0;
+#ifdef FM_STAMPS
+    unsigned long long acc_i = 0, acc_c = 0, acc_w = 0, acc_b = 0, acc_n = 0;
+#endif
     for (; c + D <= last; ++c) {                                // steady state: window c + D exists
+        FM_T(t0);
         issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        FM_T(t1);
         compute(slot);
+        FM_T(t2);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
+        FM_T(t3);
         __builtin_amdgcn_s_barrier();
+#ifdef FM_STAMPS
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        acc_i += t1 - t0; acc_c += t2 - t1; acc_w += t3 - t2; acc_b += t4 - t3; acc_n += 1;
+#endif
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+#ifdef FM_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_fm_stamps[0], acc_i); atomicAdd(&g_fm_stamps[1], acc_c); atomicAdd(&g_fm_stamps[2], acc_w);
+        atomicAdd(&g_fm_stamps[3], acc_b); atomicAdd(&g_fm_stamps[4], acc_n);
+    }
+#endif
     for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
         compute(slot);
         if (c < last) {
@@ -259,13 +302,13 @@ __device__ __forceinline__ void fm_run_channels_plain(const float* __restrict__ 
     const int wave_first = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
     const unsigned ring_lds = (unsigned)(uintptr_t)(fm_lptr_t)ring;
     const unsigned pitch4 = 4u * (unsigned)win.pitch;
-    unsigned lb[NE], soff[NE];
+    unsigned lb[NE], pix4[FM_PX];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int p = 0; p < FM_PX; ++p) {
             lb[t * FM_PX + p] = ring_lds + 4u * (unsigned)px[p].lbase[t];       // (an invalid evaluation's reads land anywhere: discarded)
-            soff[t * FM_PX + p] = px[p].valid[t] ? 4u * px[p].pix : 0x80000000u;   // (its store is dropped by the range check)
+            pix4[p] = 4u * px[p].pix;
         }
     // filter taps as (left quadrant, right quadrant) pairs: rows 0-1 feed the top sums, rows 2-3 the bottom ones (two flows;
     // with three, 16 more aligned register pairs are more than the allocator places without spilling inside the loop)
@@ -339,7 +382,9 @@ __device__ __forceinline__ void fm_run_channels_plain(const float* __restrict__ 
             asm volatile("" : "+v"(al), "+v"(be));
             const float val = blend4(al, be, top.x, top.y, bot.x, bot.y);
             const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[e], 0, 0);
+            unsigned po = pix4[p];                          // (an invalid evaluation's store is dropped by the range check)
+            asm volatile("" : "+v"(po));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
             if constexpr (OVERLAP) {
                 if constexpr (e + 1 < NE) reads(std::integral_constant<int, e + 1>{}, I1{});
                 if constexpr (e + 2 < NE) reads(std::integral_constant<int, e + 2>{}, I0{});
@@ -471,10 +516,11 @@ __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
     // the slot holds pairs (column c, column c + 2): bw - 2 of them per row, pitch a multiple of 32 pairs; a window too large
     // for that is staged plain (pitch a multiple of 32 dwords)
     const int bwp = any_valid ? bw - 2 : 0;
-    const int pitch_pairs = (bwp + 31) & ~31;
-    const bool paired = (2 * pitch_pairs * bh + FM_THREADS - 1) / FM_THREADS <= kpair;      // (kpair <= FM_KPAIR)
-    const int pitch = paired ? pitch_pairs : (bw + 31) & ~31;
-    const int n = paired ? 2 * pitch * bh : pitch * bh;     // dwords
+    const int segs = max(3, (bwp + 31) >> 5);                // S: segments of 32 pairs per row (a narrow window takes the class of 3)
+    const int rows8 = max(3, (bh + 7) >> 3);                 // KR: rows per staging wave
+    const bool paired = segs <= 4 && segs * rows8 <= kpair;  // (kpair <= FM_KPAIR)
+    const int pitch = paired ? 32 * segs : (bw + 31) & ~31;
+    const int n = paired ? 0 : pitch * bh;                   // dwords of a plain window
 #pragma unroll
     for (int p = 0; p < FM_PX; ++p)
 #pragma unroll
@@ -502,17 +548,18 @@ __global__ __launch_bounds__(FM_THREADS, 4) void fi_forward_ori_multi(
 
     const FmWindow win{bx0, by0, paired ? bwp : bw, bh, pitch, h, w, (int)s1.h};
     float* ring = lds + FM_HDR;
-#define FM_RUN(K) fm_run_channels<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
+#define FM_RUN(S, KR) fm_run_channels<S, KR, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
 #define FM_RUN_PLAIN(K) fm_run_channels_plain<K, NT>(img, ptr, boff, s1.c, c_begin, c_end, tid, win, px, ring)
-    // (a whole 64 x 16 tile needs at least 67 x 19 elements = 96 x 19 pairs: K >= 8)
     if (paired) {
-        if (kmax <= 6) FM_RUN(6);
-        else if (kmax <= 8) FM_RUN(8);
-        else if (kmax == 9) FM_RUN(9);
-        else if (kmax == 10) FM_RUN(10);
-        else if (kmax == 11) FM_RUN(11);
-        else if (kmax == 12) FM_RUN(12);
-        else FM_RUN(13);
+        if (segs == 3) {
+            if (rows8 == 3) FM_RUN(3, 3);
+            else if (rows8 == 4) FM_RUN(3, 4);
+            else if (rows8 == 5) FM_RUN(3, 5);
+            else FM_RUN(3, 6);
+        } else {
+            if (rows8 == 3) FM_RUN(4, 3);
+            else FM_RUN(4, 4);
+        }
     } else {
         if (kmax <= 8) FM_RUN_PLAIN(8);
         else if (kmax <= 10) FM_RUN_PLAIN(10);
@@ -534,8 +581,22 @@ extern "C" int vfi_filterinterp_forward_ori(const float* input1, const float* in
 
 // largest staged dwords per thread a window may need as pairs (development builds: 0 = every window plain)
 VFI_KNOB(int, g_fm_kpair, FM_KPAIR);
+// flows per launch, at most (2 or 3)
+VFI_KNOB(int, g_fm_group, FM_GROUP);
 #ifdef VFI_DEV
-extern "C" void vfi_dev_multi(int kpair) { g_fm_kpair = kpair < FM_KPAIR ? kpair : FM_KPAIR; }
+extern "C" void vfi_dev_multi(int kpair, int group) {
+    g_fm_kpair = kpair < FM_KPAIR ? kpair : FM_KPAIR;
+    if (group == 2 || group == 3) g_fm_group = group;
+}
+#endif
+#ifdef FM_STAMPS
+// reads the accumulators and clears them (synchronises)
+extern "C" int vfi_dev_multi_stamps(unsigned long long* host8) {
+    if (hipDeviceSynchronize() != hipSuccess) return VFI_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_fm_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return VFI_ERR_LAUNCH;
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fm_stamps), zero, sizeof(zero)) == hipSuccess ? VFI_OK : VFI_ERR_LAUNCH;
+}
 #endif
 
 extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const float* const* flows, const float* input3,
@@ -547,10 +608,10 @@ extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const flo
     if (!input1 || !input3) return VFI_ERR_SHAPE;
     for (int t = 0; t < nflows; ++t)
         if (!flows[t] || !outputs[t]) return VFI_ERR_SHAPE;
-    // more flows than one launch takes: groups of three, the rest as a pair or alone
-    if (nflows > FM_MAXT) {
+    // more flows than one launch takes: groups of g_fm_group, the rest as a pair or alone
+    if (nflows > g_fm_group) {
         for (int t0 = 0; t0 < nflows;) {
-            const int n = (nflows - t0 == FM_MAXT + 1) ? 2 : (nflows - t0 < FM_MAXT ? nflows - t0 : FM_MAXT);
+            const int n = (g_fm_group == 3 && nflows - t0 == 4) ? 2 : (nflows - t0 < g_fm_group ? nflows - t0 : g_fm_group);
             const int err = vfi_filterinterp_forward_ori_multi(input1, flows + t0, input3, outputs + t0, n, batch, channel, h, w,
                                                                filter_channels, s1, s2, s3, stream);
             if (err != VFI_OK) return err;

@@ -87,9 +87,10 @@ int fi_channel_groups(int ntiles, int channel, double prologue);
 // atomics arrive in, so two runs differ in the last bits.  Here every addend is scaled by ONE power of two per call,
 // rounded to an integer and added with a 64-bit INTEGER atomic into a scratch plane; a last pass converts the exact
 // integer sums to float once and adds them to the caller's (zero-filled) gradient.  Order-free, hence reproducible bit
-// for bit.  The scale is 2^(62 - ceil(log2(h w)) - eg - ew) with 2^eg > max |gradoutput| and 2^ew > max |tap weight|
-// (the filter tensor; 1 where the weights are bilinear fractions only): an addend is below 2^(62 - ceil(log2(h w))) and
-// even a cell that EVERY pixel of the frame hits stays inside 63 bits -- no combination of finite inputs overflows.
+// for bit.  The scale is 2^(62 - ceil(log2(h w T)) - eg - ew) with 2^eg > max |gradoutput|, 2^ew > max |tap weight|
+// (the filter tensor; 1 where the weights are bilinear fractions only) and T = the taps of a pixel (fs x fs; 4 for a
+// bilinear sample): an addend is below 2^(62 - ceil(log2(h w T))) and even a cell that EVERY tap of EVERY pixel of the frame
+// hits (border clamping folds a pixel's taps onto one cell) stays inside 63 bits -- no combination of finite inputs overflows.
 // Non-finite inputs: the first pass raises a flag when gradoutput or the weights hold a NaN or an infinity, and the
 // kernels then scatter with the reference's own fp32 atomics for that call (NaN / Inf propagate to exactly the cells
 // the reference would poison; the integer path would turn them into finite garbage).
@@ -97,7 +98,7 @@ int fi_channel_groups(int ntiles, int channel, double prologue);
 //           ->  gradacc_finish
 //   device: gradacc_ctx(hdr) once per thread, gradacc_add(...) per addend; cells are indexed densely [b][c][y][x] whatever
 //           the strides of the gradient tensor.
-// hdr words: [0] bits of max |gradoutput|, [1] non-finite flag, [2] bits of max |weight| (0: none given), [3] ceil(log2(h w))
+// hdr words: [0] bits of max |gradoutput|, [1] non-finite flag, [2] bits of max |weight| (0: none given), [3] ceil(log2(h w T))
 struct GradAccCtx { float scale; bool nonfinite; };
 __device__ __forceinline__ int gradacc_exponent(const int* __restrict__ hdr) {
     int eg = 0, ew = 1;                                     // no weight tensor: |weight| <= 1 < 2^1
@@ -118,7 +119,8 @@ __device__ __forceinline__ void gradacc_add(unsigned long long* acc_plane, float
     if (cx.nonfinite) atomicAdd(&g_plane[gi], v);
     else atomicAdd(&acc_plane[di], (unsigned long long)__float2ll_rn(v * cx.scale));
 }
-// weights (may be null): a [batch, wchannel, h, w] tensor whose largest |element| bounds the tap weights;
+// weights (may be null): a [batch, wchannel, h, w] tensor whose largest |element| bounds the tap weights; wchannel = the taps
+// of a pixel (also when weights is null; below 4: 4);
 // nflags / flags: that many zeroed words of the same scratch for the caller's kernels (flags may be null)
 int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int h, int w, vfi_strides sg,
                   const float* weights, int wchannel, vfi_strides sw, unsigned long long** acc, int** hdr,

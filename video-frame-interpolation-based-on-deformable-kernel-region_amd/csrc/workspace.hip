@@ -152,8 +152,12 @@ int gradacc_begin(hipStream_t st, const float* gout, int batch, int channel, int
     *hdr = static_cast<int*>(p);
     *acc = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + 256);
     if (flags) *flags = reinterpret_cast<int*>(static_cast<char*>(p) + 256 + (size_t)n * 8);
+    // addends one cell can receive: every pixel of the frame, with every one of its taps -- border clamping can put all fs x fs
+    // taps of a pixel (the four corners of a bilinear sample) on one cell (h w alone left (9/4) h w addends of
+    // nearly 2^(62 - L) possible on a corner cell at fs = 6)
+    const int64_t taps = wchannel > 4 ? wchannel : 4;
     int cells_log2 = 0;
-    while (((int64_t)1 << cells_log2) < (int64_t)h * w) ++cells_log2;
+    while (((int64_t)1 << cells_log2) < (int64_t)h * w * taps) ++cells_log2;
     const int64_t rows = n / w;
     const int blocks = (int)(rows < 2048 ? rows : 2048);
     hipLaunchKernelGGL(gradacc_max, dim3(blocks), dim3(256), 0, st, gout, channel, h, w, sg, n, *hdr, 0, cells_log2);

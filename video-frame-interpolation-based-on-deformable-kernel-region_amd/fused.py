@@ -28,6 +28,13 @@ class DirectionStreams:
             with ds.direction(d):       # d = 0: the current stream; d = 1: the side stream
                 ...                     # direction d's calls
         ds.join()                       # the current stream continues when both are done
+
+    Memory across the two streams (torch's caching allocator keeps one pool per stream): a tensor allocated inside
+    `with ds.direction(1)` belongs to the side stream's pool and is consumed on the current stream after `join()`; inputs
+    allocated on the current stream are read on the side stream after `fork()`.  That is safe as long as such a tensor stays
+    alive until the next `fork()` / `join()` has ordered the streams again -- a tensor freed earlier can be handed out again
+    on the OTHER stream while launches that use it are still in flight.  Either pre-allocate what crosses the streams (what
+    `bench.py` does), or call `tensor.record_stream(stream)` on it; `join(*tensors)` does the latter for the tensors it is given.
     """
 
     def __init__(self, device=None):
@@ -44,9 +51,13 @@ class DirectionStreams:
             raise RuntimeError("DirectionStreams.fork() first: the side stream must be ordered after the inputs")
         return torch.cuda.stream(torch.cuda.current_stream(self.device) if d == 0 else self.side)
 
-    def join(self):
+    def join(self, *tensors):
+        """`tensors`: results of direction 1 that the current stream goes on to use (recorded on it for the allocator)"""
         if self._forked:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.side)
+            for t in tensors:
+                t.record_stream(cur)
             self._forked = False
 
 
