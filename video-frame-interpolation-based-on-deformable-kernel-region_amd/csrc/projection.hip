@@ -76,9 +76,9 @@ namespace vfi {
 // workspace "words" (32-bit).  Header: [0] a block of this call reaches too many tiles: fallback (set by K0,
 // read by K1, reset by K2); [2] the scratch planes of the fallback hold sums (written by K1, read by K2 and by
 // the next call's K0).
-// Then one 8-word record per output tile: its source rectangle as 32767 - x0, 32767 - y0, x1 + 1, y1 + 1 and
-// the bits of the largest |value addend| and |count addend| that reach it -- all merged with atomicMax by K0,
-// so 0 = nothing; K1 reads its record and zeroes it again.  Then one word per tile from K1 to K2: has it holes.
+// Then one 8-word record per output tile: its source rectangle as 32767 - x0, 32767 - y0, x1 + 1, y1 + 1, the bits of the
+// largest |fx|, of the largest |count addend| and (inverted) of the smallest weight that reach it, and the bits of the largest
+// |fy| -- all merged with atomicMax by K0, so 0 = nothing; K1 reads its record and zeroes it again.  Then one word per tile from K1 to K2: has it holes.
 // workspace "bits": two bitmaps of "count != 0", one packed along rows (rowmap[b][y][x/32]) and one packed
 // along columns (colmap[b][x][y/32], lines padded to whole 16-byte groups), written by K1 for the hole filler.
 #define PROJ_WS_HDR 16
@@ -234,7 +234,7 @@ __device__ __forceinline__ int row16_max(int v) {
 // instruction (lane k = field k) -- the atomics are the expensive part of this kernel (one wave instruction
 // per ~50 ns per CU at the memory side, whatever its lane count).
 __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict__ ws, int b, int lane, int x, int y0,
-                                             int dlmin, int dlmax, int dtmin, int dtmax, int vbits, int cbits, int mbits) {
+                                             int dlmin, int dlmax, int dtmin, int dtmax, int vbits, int cbits, int mbits, int fbits) {
     const bool any = dlmin != INT_MAX;
     const int bx0 = x - 15, bx1 = min(x, g.w - 1), by1 = min(y0 + PROJ_BLK - 1, g.h - 1);
     // top-left targets of the block lie in [X0, X1] x [Y0, Y1]; a target (L, T) feeds columns L, L + 1, rows T, T + 1
@@ -261,7 +261,7 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
             const int sy0 = max(y0, oy0 - 1 - dtmax), sy1 = min(by1, ty1 - dtmin);
             const bool hit = any && sx0 <= sx1 && sy0 <= sy1;
             // fields as stored (0 = nothing), merged over the four blocks
-            int f0m = 0, f1m = 0, f2m = 0, f3m = 0, f4m = 0, f5m = 0, f6m = 0;
+            int f0m = 0, f1m = 0, f2m = 0, f3m = 0, f4m = 0, f5m = 0, f6m = 0, f7m = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int sl = 16 * q + 15;
@@ -270,11 +270,12 @@ __device__ __forceinline__ void scan_scatter(const ProjGeom& g, int* __restrict_
                 f2m = max(f2m, __builtin_amdgcn_readlane(sx1, sl) + 1); f3m = max(f3m, __builtin_amdgcn_readlane(sy1, sl) + 1);
                 f4m = max(f4m, __builtin_amdgcn_readlane(vbits, sl)); f5m = max(f5m, __builtin_amdgcn_readlane(cbits, sl));
                 f6m = max(f6m, __builtin_amdgcn_readlane(mbits, sl));
+                f7m = max(f7m, __builtin_amdgcn_readlane(fbits, sl));
             }
             if (f2m == 0) continue;
             int* e = ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS;
-            const int v = lane == 0 ? f0m : lane == 1 ? f1m : lane == 2 ? f2m : lane == 3 ? f3m : lane == 4 ? f4m : lane == 5 ? f5m : f6m;
-            if (lane < 7) atomicMax(&e[lane], v);
+            const int v = lane == 0 ? f0m : lane == 1 ? f1m : lane == 2 ? f2m : lane == 3 ? f3m : lane == 4 ? f4m : lane == 5 ? f5m : lane == 6 ? f6m : f7m;
+            if (lane < 8) atomicMax(&e[lane], v);
         }
 }
 
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
     const int xc = min(x, g.w - 1);
     const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
-    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0, fbits = 0;
     constexpr int GROUP = PROJ_TH;                          // rows whose loads are issued together
 #pragma unroll 1
     for (int r0 = 0; r0 < PROJ_TH; r0 += GROUP) {
@@ -318,9 +319,11 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
             const int dl = L - x, dt = T - y;
             dlmin = min(dlmin, valid ? dl : INT_MAX); dlmax = max(dlmax, valid ? dl : INT_MIN);
             dtmin = min(dtmin, valid ? dt : INT_MAX); dtmax = max(dtmax, valid ? dt : INT_MIN);
-            // the largest |flow| and, with depth, the largest and the smallest |weight| (the latter stored inverted, so
-            // that "largest" merges it); non-negative floats order like their bit patterns
-            vbits = max(vbits, valid ? __float_as_int(fmaxf(fabsf(fx), fabsf(fy))) : 0);
+            // the largest |fx| and |fy| (each component gets its own fixed-point scale) and, with depth, the largest and the
+            // smallest |weight| (the latter stored inverted, so that "largest" merges it); non-negative floats order like
+            // their bit patterns
+            vbits = max(vbits, valid ? __float_as_int(fabsf(fx)) : 0);
+            fbits = max(fbits, valid ? __float_as_int(fabsf(fy)) : 0);
             if constexpr (DEPTH) {
                 const int db = __float_as_int(fabsf(raw[k].d));
                 cbits = max(cbits, valid ? db : 0);
@@ -330,8 +333,8 @@ __global__ __launch_bounds__(64) void proj_scan(ProjSrc src, ProjGeom g, int* __
     }
     dlmin = row16_min(dlmin); dlmax = row16_max(dlmax);
     dtmin = row16_min(dtmin); dtmax = row16_max(dtmax);
-    vbits = row16_max(vbits); cbits = row16_max(cbits); mbits = row16_max(mbits);
-    scan_scatter(g, ws, b, lane, x, y0, dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits);
+    vbits = row16_max(vbits); cbits = row16_max(cbits); mbits = row16_max(mbits); fbits = row16_max(fbits);
+    scan_scatter(g, ws, b, lane, x, y0, dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits, fbits);
 }
 
 // K0 for a full-resolution flow: the same, with 16-byte lanes (a walk with 4-byte lanes reaches ~4 TB/s on this
@@ -351,10 +354,10 @@ __device__ __forceinline__ int quad_max(int v) { PROJ_QUAD_STEP(max, 0xb1); PROJ
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int groups_x, int* __restrict__ ws,
                                                   float* __restrict__ planes, int64_t plane_floats) {
-    __shared__ int sblk[16][7];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits
+    __shared__ int sblk[16][8];                             // per block: dlmin, dlmax, dtmin, dtmax, vbits, cbits, mbits, fbits
     __shared__ __attribute__((aligned(16))) int stab[PROJ_STAB * PROJ_STAB][8];   // the workgroup's merged updates: [tile slot][record field]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 112) sblk[tid / 7][tid % 7] = (tid % 7 == 0 || tid % 7 == 2) ? INT_MAX : (tid % 7 == 1 || tid % 7 == 3) ? INT_MIN : 0;
+    if (tid < 128) sblk[tid >> 3][tid & 7] = ((tid & 7) == 0 || (tid & 7) == 2) ? INT_MAX : ((tid & 7) == 1 || (tid & 7) == 3) ? INT_MIN : 0;
     reinterpret_cast<uint4*>(&stab[tid][0])[0] = make_uint4(0u, 0u, 0u, 0u);
     reinterpret_cast<uint4*>(&stab[tid][0])[1] = make_uint4(0u, 0u, 0u, 0u);
     const int per_img = groups_x * g.tiles_y;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) planes[i] = 0.0f;
     }
     __syncthreads();
-    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0;
+    int dlmin = INT_MAX, dlmax = INT_MIN, dtmin = INT_MAX, dtmax = INT_MIN, vbits = 0, cbits = 0, mbits = 0, fbits = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -393,9 +396,10 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
             if (valid) {
                 dlmin = min(dlmin, L - x); dlmax = max(dlmax, L - x);
                 dtmin = min(dtmin, T - y); dtmax = max(dtmax, T - y);
-                // the largest |flow|, the largest and (inverted) the smallest |weight|; non-negative floats order like
-                // their bit patterns
-                vbits = max(vbits, __float_as_int(fmaxf(fabsf(fx), fabsf(fy))));
+                // the largest |fx| and |fy|, the largest and (inverted) the smallest |weight|; non-negative floats order
+                // like their bit patterns
+                vbits = max(vbits, __float_as_int(fabsf(fx)));
+                fbits = max(fbits, __float_as_int(fabsf(fy)));
                 if constexpr (DEPTH) {
                     const int db = __float_as_int(fabsf(qd[r][j]));
                     cbits = max(cbits, db);
@@ -408,11 +412,11 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
 #endif
     // a block is four lanes wide
     dlmin = quad_min(dlmin); dlmax = quad_max(dlmax); dtmin = quad_min(dtmin); dtmax = quad_max(dtmax);
-    vbits = quad_max(vbits); cbits = quad_max(cbits); mbits = quad_max(mbits);
+    vbits = quad_max(vbits); cbits = quad_max(cbits); mbits = quad_max(mbits); fbits = quad_max(fbits);
     if ((lane & 3) == 0 && dlmin != INT_MAX) {
         int* e = sblk[lane >> 2];
         atomicMin(&e[0], dlmin); atomicMax(&e[1], dlmax); atomicMin(&e[2], dtmin); atomicMax(&e[3], dtmax);
-        atomicMax(&e[4], vbits); atomicMax(&e[5], cbits); atomicMax(&e[6], mbits);
+        atomicMax(&e[4], vbits); atomicMax(&e[5], cbits); atomicMax(&e[6], mbits); atomicMax(&e[7], fbits);
     }
     __syncthreads();
     // The tail (round 3).  Thread (block k, slot j): block k of the workgroup's 16 and the j-th of the <= 2 x 8 output tiles it
@@ -446,15 +450,15 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
             const int sx0 = max(bx0, ox0 - 1 - dlmax_), sx1 = min(bx1, tx1 - dlmin_);
             const int sy0 = max(y0, oy0 - 1 - dtmax_), sy1 = min(by1, ty1 - dtmin_);
             if (sx0 > sx1 || sy0 > sy1) return;
-            const int f[7] = {32767 - sx0, 32767 - sy0, sx1 + 1, sy1 + 1, e[4], e[5], e[6]};
+            const int f[8] = {32767 - sx0, 32767 - sy0, sx1 + 1, sy1 + 1, e[4], e[5], e[6], e[7]};
             const int rx = tx - torg_x, ry = ty - torg_y;
             if ((unsigned)rx < PROJ_STAB && (unsigned)ry < PROJ_STAB) {
 #pragma unroll
-                for (int q = 0; q < 7; ++q) atomicMax(&stab[ry * PROJ_STAB + rx][q], f[q]);
+                for (int q = 0; q < 8; ++q) atomicMax(&stab[ry * PROJ_STAB + rx][q], f[q]);
             } else {                                            // beyond the table (flows of hundreds of pixels): straight to the record
                 int* rec = ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS;
 #pragma unroll
-                for (int q = 0; q < 7; ++q) atomicMax(&rec[q], f[q]);
+                for (int q = 0; q < 8; ++q) atomicMax(&rec[q], f[q]);
             }
         };
         if (any && !wild && !wide) {
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void proj_scan4(ProjSrc src, ProjGeom g, int g
         for (int pass = 0; pass < PROJ_STAB * PROJ_STAB / 32; ++pass) {
             const int sl = 32 * pass + (tid >> 3), q = tid & 7;
             const int v = stab[sl][q];
-            if (v != 0 && q < 7) {
+            if (v != 0) {
                 const int tx = torg_x + (sl % PROJ_STAB), ty = torg_y + (sl / PROJ_STAB);
                 atomicMax(ws + g.off_tile + (int64_t)((b * g.tiles_y + ty) * g.tiles_x + tx) * PROJ_TILE_WORDS + q, v);
             }
@@ -588,7 +592,7 @@ __device__ __forceinline__ void pull_bitmaps(const ProjGeom& g, int* __restrict_
 template <bool DEPTH>
 __device__ __forceinline__ void pull_add(unsigned long long* accv, typename ProjCountCell<DEPTH>::type* accc,
                                          float fx, float fy, float d, int px, int py, bool on, unsigned wbits, unsigned hbits,
-                                         int cx, int cy, float sv, float scn, int cls, int ncls, int emax) {
+                                         int cx, int cy, float svx, float svy, float scn, int cls, int ncls, int emax) {
     int L, T;
     bool valid = pix_target(fx, fy, px, py, wbits, hbits, L, T);
     if constexpr (DEPTH) {
@@ -598,13 +602,13 @@ __device__ __forceinline__ void pull_add(unsigned long long* accv, typename Proj
     }
     const unsigned c = (unsigned)(L - cx), r = (unsigned)(T - cy);
 #if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 3
-    if (valid && on && c < PROJ_AW && r < PROJ_AH && sv == 12345.0f) {
+    if (valid && on && c < PROJ_AW && r < PROJ_AH && svx == 12345.0f) {
 #else
     if (valid && on && c < PROJ_AW && r < PROJ_AH) {
 #endif
         // addend * 2^k is exact in float (power-of-two scale)
         const float ax = DEPTH ? d * fx : fx, ay = DEPTH ? d * fy : fy;        // (:75-88; depth :74-91)
-        atomicAdd(&accv[r * PROJ_VS + c], pack2(__float2int_rn(ax * sv), __float2int_rn(ay * sv)));
+        atomicAdd(&accv[r * PROJ_VS + c], pack2(__float2int_rn(ax * svx), __float2int_rn(ay * svy)));
         if constexpr (DEPTH) atomicAdd(&accc[r * PROJ_VS + c], pack2(1, __float2int_rn(d * scn)));
         else atomicAdd(&accc[r * PROJ_CS4 + c], 1u);
     }
@@ -639,20 +643,20 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         ws[PROJ_WS_DIRTY + 1] = fallback ? (int)(plane_floats >> 32) : 0;
     }
     int* entry = ws + g.off_tile + (int64_t)tile * PROJ_TILE_WORDS;
-    const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5], e6 = entry[6];
+    const int e0 = entry[0], e1 = entry[1], e2 = entry[2], e3 = entry[3], e4 = entry[4], e5 = entry[5], e6 = entry[6], e7 = entry[7];
     const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     const unsigned wbits = (unsigned)__float_as_int((float)(g.w - 1)), hbits = (unsigned)__float_as_int((float)(g.h - 1));
 
     if (fallback) {
         __syncthreads();
-        if (tid < 7) entry[tid] = 0;
+        if (tid < 8) entry[tid] = 0;
         pull_fallback<DEPTH, PROJ_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
         return;
     }
 
     for (int i = tid; i < ProjLds<DEPTH>::total / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    if (tid < 7) entry[tid] = 0;                            // every thread has read the record: empty for the next call
+    if (tid < 8) entry[tid] = 0;                            // every thread has read the record: empty for the next call
 #ifdef PROJ_STAMPS
     const unsigned long long st_ta = __builtin_amdgcn_s_memtime() + (e0 & 0);      // (after the record has arrived)
 #endif
@@ -660,19 +664,20 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     const int ux0 = 32767 - e0, uy0 = 32767 - e1;
     const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
     // Fixed-point scales: a value addend is below 2^(ef + ec) and a weight below 2^ec, with 2^ef / 2^ec above the
-    // largest |flow| / |weight| that can reach this tile (from K0), so addend * 2^(25 - e) is below 2^25.
+    // largest |fx| or |fy| (a scale per component: proj_pull_lean) / |weight| that can reach this tile (from K0), so
+    // addend * 2^(25 - e) is below 2^25.
     // DepthFlowProjection: the weights (inverse depth, 1e-6 + exp(-d): DAIN_slowmotion.py:143) can span many
     // orders of magnitude inside one tile, e.g. at the edge of a near object in front of sky, and a cell that only
     // far-away sources reach must still get full relative precision (the reference's fp32 sums give it that).  So
     // the sources are taken in up to four passes by weight class -- class j: weights within 2^(-6 j) .. 2^(-6 j - 6)
     // of the largest, the last class everything below -- each pass with its own scale, exact integer sums, one
     // rounding to float, and the classes' results are added.  Almost every tile has one class.
-    int ef = 0, ec = 0;
-    (void)frexpf(__int_as_float(e4), &ef);
+    int efx = 0, efy = 0, ec = 0;
+    (void)frexpf(__int_as_float(e4), &efx);
+    (void)frexpf(__int_as_float(e7), &efy);
     if constexpr (DEPTH) (void)frexpf(__int_as_float(e5), &ec);
     const int emax = (e5 >> 23) & 0xff, emin = e6 ? ((PROJ_INV_BITS - e6) >> 23) & 0xff : emax;
     const int ncls = DEPTH ? min(4, max(0, emax - emin) / PROJ_CLS_BITS + 1) : 1;
-
     // epilogue geometry: a lane owns four consecutive cells of a row, 16 lanes a row, a wave four rows
     const int q = lane & 15, rw = lane >> 4;
     const int xq = ox0 + 4 * q;
@@ -712,9 +717,10 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
     constexpr bool FIRST = decltype(first_tag)::value;
     // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
     int kc = max(-100, min(100, PROJ_ADD_BITS - (ec - PROJ_CLS_BITS * cls)));
-    int kv = max(-100, min(100, PROJ_ADD_BITS - (ef + ec - PROJ_CLS_BITS * cls)));
+    int kvx = max(-100, min(100, PROJ_ADD_BITS - (efx + ec - PROJ_CLS_BITS * cls)));
+    int kvy = max(-100, min(100, PROJ_ADD_BITS - (efy + ec - PROJ_CLS_BITS * cls)));
     for (int attempt = 0;; ++attempt) {
-        const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
+        const float svx = -ldexpf(1.0f, kvx), svy = -ldexpf(1.0f, kvy), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
         // The rectangle is walked in strips of up to 64 lanes.  A full strip: the workgroup's waves take its rows
         // in turn (row base and flow row pointer advance on the scalar unit: no per-pixel index arithmetic).  A
         // narrower strip packs 64 / width rows into a wave the same way.  Rows past the rectangle are not loaded.
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
                     for (int k = 0; k < CH; ++k) {
                         const int rowk = row0 + k * step + lr;
                         const int py = uy0 + rowk;
-                        pull_add<DEPTH>(accv, accc, raw[k].fx, raw[k].fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, sv, scn,
+                        pull_add<DEPTH>(accv, accc, raw[k].fx, raw[k].fy, raw[k].d, px, py, lane_on && rowk < uh, wbits, hbits, ox0 - 1, oy0 - 1, svx, svy, scn,
                                         cls, ncls, emax);
                     }
                 }
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
 #pragma unroll
                         for (int j = 0; j < 4; ++j)                         // (a quad may reach past the row: x < w)
                             pull_add<DEPTH>(accv, accc, qx[k][j], qy[k][j], qd[k][j], px + j, uy0 + rowk, on && px + j < g.w, wbits, hbits,
-                                            ox0 - 1, oy0 - 1, sv, scn, cls, ncls, emax);
+                                            ox0 - 1, oy0 - 1, svx, svy, scn, cls, ncls, emax);
                     }
                 }
             }
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         if (nmax <= PROJ_ADD_CELL) break;
         // once more with addends small enough for the busiest cell
         const int shift = (32 - __clz(nmax - 1)) - 5;           // ceil(log2(nmax)) - log2(32)
-        kv -= shift; kc -= shift;
+        kvx -= shift; kvy -= shift; kc -= shift;
         for (int i = tid; i < ProjLds<DEPTH>::acc_bytes / 16; i += PROJ_PULL_THREADS) lds[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
             if (xlast) { h0 += a[0][j + 1]; h1 += a[1][j + 1]; }
             unsigned long long v = h0 + h1;
             if (ylast) v += h1;
-            const float px_ = ldexpf((float)packed_hi(v), -kv), py_ = ldexpf((float)packed_lo(v), -kv);
+            const float px_ = ldexpf((float)packed_hi(v), -kvx), py_ = ldexpf((float)packed_lo(v), -kvy);
             float pc_;
             if constexpr (DEPTH) pc_ = ldexpf((float)packed_lo(c4[j]), -kc); else pc_ = (float)c4[j];
             if constexpr (FIRST) { resx[it][j] = px_; resy[it][j] = py_; resc[it][j] = pc_; }
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(PROJ_PULL_THREADS, PROJ_PULL_WAVES) void proj_pull(
         }
         if (nzb) atomicOr(&s_rowbits[yl * 2 + (q >> 3)], nzb << ((q & 7) * 4));
 #if defined(PROJ_STAMPS) && PROJ_DEV_SKIP == 2
-        if (y < g.h && kv == 12345) {
+        if (y < g.h && ncls == 12345) {
 #else
         if (y < g.h) {
 #endif
@@ -1033,21 +1039,25 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
     }
     const ProjPlanes pl = proj_planes<DEPTH>(src, b, g.h, g.w);
     __syncthreads();
-    if (tid < 7) entry[tid] = 0;                            // the record is in registers: empty for the next call
+    if (tid < 8) entry[tid] = 0;                            // the record is in registers: empty for the next call
     if (fallback) {
         pull_fallback<DEPTH, PL_NW>(src, pl, g, planes, b, ox0, oy0, lane, wave);
         return;
     }
 
-    const int e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3], e4 = rec[4], e5 = rec[5], e6 = rec[6];
+    const int e0 = rec[0], e1 = rec[1], e2 = rec[2], e3 = rec[3], e4 = rec[4], e5 = rec[5], e6 = rec[6], e7 = rec[7];
     const int ux0 = 32767 - e0, uy0 = 32767 - e1;
     const int uw = e2 - ux0, uh = e2 > 0 ? e3 - uy0 : 0;    // uh == 0: nothing lands here
-    int ef = 0, ec = 0;                                     // (see proj_pull: scales and weight classes)
-    (void)frexpf(__int_as_float(e4), &ef);
+    // Fixed-point scales (see proj_pull for the weight classes).  Each flow component has its own: a tile's x scale follows the
+    // largest |fx| that reaches it, its y scale the largest |fy|, so a component that is small all over the tile's sources --
+    // the zero crossings of a smooth field, a pan along one axis -- keeps its own precision beside a large other component
+    // (one common scale left 1.6e-4 px on such cells under 256-pixel flows; SURVEY's tolerance is 1e-4).
+    int efx = 0, efy = 0, ec = 0;
+    (void)frexpf(__int_as_float(e4), &efx);
+    (void)frexpf(__int_as_float(e7), &efy);
     if constexpr (DEPTH) (void)frexpf(__int_as_float(e5), &ec);
     const int emax = (e5 >> 23) & 0xff, emin = e6 ? ((PROJ_INV_BITS - e6) >> 23) & 0xff : emax;
     const int ncls = DEPTH ? min(4, max(0, emax - emin) / PROJ_CLS_BITS + 1) : 1;
-
     // one interval per axis: valid target and inside the grid (columns ox0 - 1 .. ox0 + 63, rows oy0 - 1 .. oy0 + 15)
     const float lox = (float)max(ox0 - 1, 0), loy = (float)max(oy0 - 1, 0);
     const float hix = fminf((float)(g.w - 1), __uint_as_float(__float_as_uint((float)(ox0 + PROJ_TW)) - 1u));
@@ -1116,9 +1126,9 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
     };
 
     // one weight class into the grid: every source pixel of the rectangle, once, at its top-left target
-    auto accumulate = [&](int cls, int kv, int kc) {
+    auto accumulate = [&](int cls, int kvx, int kvy, int kc) {
         constexpr int CH = PL_CH;
-        const float sv = -ldexpf(1.0f, kv), scn = ldexpf(1.0f, kc);        // exact powers of two (the value addend is MINUS the flow)
+        const float svx = -ldexpf(1.0f, kvx), svy = -ldexpf(1.0f, kvy), scn = ldexpf(1.0f, kc);    // exact powers of two (the value addend is MINUS the flow)
         const int ux0a = ux0 & ~3;                                          // quads start at multiples of four pixels
 #if PROJ_DEV_SKIP == 1      // (development: timing of the kernel without its source walk)
         const int nq = 0;
@@ -1170,13 +1180,13 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
                                 }
                             }
 #if PROJ_DEV_SKIP == 3
-                            hit = hit && sv == 12345.0f;
+                            hit = hit && svx == 12345.0f;
 #endif
                             if (hit) {
                                 const int L = (int)x2, T = (int)y2;
                                 const unsigned a = (unsigned)(__mul24(T, P) + L) * 8u + cell0;
                                 const float ax = DEPTH ? d * fx : fx, ay = DEPTH ? d * fy : fy;  // (:75-88; depth :74-91)
-                                const unsigned X = (unsigned)__float2int_rn(ax * sv), Y = (unsigned)(__float2int_rn(ay * sv) + PL_BIAS);
+                                const unsigned X = (unsigned)__float2int_rn(ax * svx), Y = (unsigned)(__float2int_rn(ay * svy) + PL_BIAS);
                                 __hip_atomic_fetch_add((pl_lds64_t)a, ((unsigned long long)X << 32) | Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 if constexpr (DEPTH) {
                                     const unsigned Wc = (unsigned)(__float2int_rn(d * scn) + PL_BIAS);
@@ -1198,7 +1208,7 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
     for (int attempt = 0;; ++attempt) {
         float resx[PL_EPI][4], resy[PL_EPI][4], resc[PL_EPI][4];
         int nres[PL_EPI][4];
-        int nmax = 0, kv = 0;
+        int nmax = 0;
         for (int cls = 0; cls < ncls; ++cls) {
             if (cls > 0) {
                 __syncthreads();                                // every lane has the previous class's sums
@@ -1207,8 +1217,9 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
             }
             // (clamped so that 2^k stays a normal float when every addend is tiny or huge)
             const int kc = max(-100, min(100, PROJ_ADD_BITS - (ec - PROJ_CLS_BITS * cls))) - shift;
-            kv = max(-100, min(100, PROJ_ADD_BITS - (ef + ec - PROJ_CLS_BITS * cls))) - shift;
-            accumulate(cls, kv, kc);
+            const int kvx = max(-100, min(100, PROJ_ADD_BITS - (efx + ec - PROJ_CLS_BITS * cls))) - shift;
+            const int kvy = max(-100, min(100, PROJ_ADD_BITS - (efy + ec - PROJ_CLS_BITS * cls))) - shift;
+            accumulate(cls, kvx, kvy, kc);
 #ifdef PROJ_STAMPS
             if (!attempt && !cls) st_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1223,15 +1234,13 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
                     const int n = chi[j];                       // addends of the cell (cells outside the frame: none)
                     nmax = max(nmax, n);
                     const int Y = (int)(vlo[j] - ((unsigned)n << PROJ_ADD_BITS));
-                    const float fxs = (float)vhi[j], fys = (float)Y;
-                    if constexpr (DEPTH) {
-                        const int Wt = (int)(clo[j] - ((unsigned)n << PROJ_ADD_BITS));
-                        const float px_ = ldexpf(fxs, -kv), py_ = ldexpf(fys, -kv), pc_ = ldexpf((float)Wt, -kc);
-                        if (cls == 0) { resx[it][j] = px_; resy[it][j] = py_; resc[it][j] = pc_; }
-                        else { resx[it][j] += px_; resy[it][j] += py_; resc[it][j] += pc_; }
-                    } else {
-                        resx[it][j] = fxs; resy[it][j] = fys; nres[it][j] = n;
-                    }
+                    // exact integer sums -> float once per class (a power-of-two scale: exact)
+                    const float px_ = ldexpf((float)vhi[j], -kvx), py_ = ldexpf((float)Y, -kvy);
+                    float pc_;
+                    if constexpr (DEPTH) pc_ = ldexpf((float)(int)(clo[j] - ((unsigned)n << PROJ_ADD_BITS)), -kc);
+                    else pc_ = 0.0f;
+                    if (cls == 0) { resx[it][j] = px_; resy[it][j] = py_; resc[it][j] = pc_; nres[it][j] = n; }
+                    else { resx[it][j] += px_; resy[it][j] += py_; resc[it][j] += pc_; nres[it][j] += n; }
                 }
             }
         }
@@ -1243,7 +1252,6 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
         // normalise (flowprojection_cuda_kernel.cu:129-134), write the tile once, 16 bytes per lane; leave the bitmaps of
         // "count != 0" for the hole filler
         int holes = 0, negs = 0;
-        const float unit = ldexpf(1.0f, kv);                    // FlowProjection: the sums are in units of 2^-kv
 #pragma unroll
         for (int it = 0; it < PL_EPI; ++it) {
             const int yl = it * 4 * PL_NW + wave * 4 + rw, y = oy0 + yl;
@@ -1259,7 +1267,7 @@ __global__ __launch_bounds__(PL_THREADS, DEPTH ? 4 : 5) void proj_pull_lean(
                     if (inside && c < 0.0f) negs += 1;
                 } else {
                     c = (float)nres[it][j];
-                    const float dd = fmaxf(c, 1.0f) * unit;     // sums / (count * 2^kv); no addends: zero sums
+                    const float dd = fmaxf(c, 1.0f);            // sums / count; no addends: zero sums
                     const float r = pl_rcp(dd);
                     vx = pl_div(resx[it][j], dd, r); vy = pl_div(resy[it][j], dd, r);
                 }
