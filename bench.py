@@ -400,6 +400,7 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
             out["roofline_quarter"] = quarter_measurement(torch, cabi, S, wl, dev, args, kernel)
         out["gate"] = gate_measurement(torch, cabi, S, wl, dev, args)
         out["fp16_storage"] = fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank)
+        out["correlation"] = correlation_measurement(torch, cabi, wl, dev)
         out["shared_window"] = shared_window_measurement(torch, cabi, wl, dev, args)
         out["best_schedule"] = best_schedule_block(out["shared_window"], value / world, max(5, args.steps // 2))
         out["as_called"] = as_called_measurement(torch, wl, dev, args, ms_per_step)
@@ -556,6 +557,24 @@ def fp16_storage_measurement(torch, cabi, S, dev, args, h, w, rank):
             "traffic": traffic_lookup(h, w, args.flow_model, False, "fi196_f16"), "algorithmic_bytes_per_launch": 856.0 * wl.px,
             "steps_timed": steps, "ms_per_step": round(step_ms, 4), "frames_per_s": round(len(TIMES) / (step_ms * 1e-3), 1),
             "step": "measured: 10 half correlations + 6 DepthFlowProjection (fp32) + 6 + 6 half-storage FilterInterpolation"}
+
+
+def correlation_measurement(torch, cabi, wl, dev, iters=100):
+    """The step's ten correlation calls (5 pyramid levels x 2 flow networks) one by one, and as five calls that take the two
+    networks' tensors of a level together (vfi_correlation_forward_pair / fused.corr_pair: at the coarse levels a launch is
+    latency); same bits."""
+    def singles(i):
+        for d in range(2):
+            for a, b in wl.corr[d]:
+                cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+
+    def pairs(i):
+        for (a0, b0), (a1, b1) in zip(wl.corr[0], wl.corr[1]):
+            cabi.correlation_forward_pair(a0, b0, a1, b1, 4, 1, 4, 1, 1)
+    nbytes = 2 * sum((2 * a.size(1) + 81) * 4.0 * a.size(2) * a.size(3) for a, _ in wl.corr[0])
+    one, two = hip_timed(torch, dev, singles, iters), hip_timed(torch, dev, pairs, iters)
+    return {"ten_calls_ms": round(one, 4), "five_pair_calls_ms": round(two, 4), "algorithmic_bytes": nbytes,
+            "pair_algorithmic_GBps": round(nbytes / (two * 1e-3) / 1e9, 1)}
 
 
 def shared_window_measurement(torch, cabi, wl, dev, args):

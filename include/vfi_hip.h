@@ -256,6 +256,16 @@ int vfi_correlation_forward(const float* input1, const float* input2, float* out
                             int pad_size, int kernel_size, int max_displacement,
                             int stride1, int stride2,
                             vfi_stream_t stream);
+/* Two forward calls of equal shape in ONE launch: the same pyramid level of the two flow networks a frame pair runs,
+ * (I0, I1) and (I1, I0) (networks/DAIN.py:196-202; PWCNet/PWCNet.py:230-300 calls the layer once per level).  At the coarse
+ * levels a launch is pure latency (13-18 us for 1 MB at 1080p) and two cost what one does.  Results: the two
+ * vfi_correlation_forward calls', bit for bit.  (Callers that batch the two orders along dim 0 need nothing new: batch = 2.) */
+int vfi_correlation_forward_pair(const float* input1_a, const float* input2_a, float* output_a,
+                                 const float* input1_b, const float* input2_b, float* output_b,
+                                 int batch, int channel, int h, int w,
+                                 int pad_size, int kernel_size, int max_displacement,
+                                 int stride1, int stride2,
+                                 vfi_stream_t stream);
 /* The reference's at::Half instantiation of the forward (correlation_cuda_kernel.cu:386, 403): inputs and output
  * IEEE half, each product rounded to half, float accumulation, mean rounded to half once. */
 int vfi_correlation_forward_f16(const void* input1_half, const void* input2_half, void* output_half,

@@ -85,6 +85,22 @@ def main():
                               % (name, model, n, label, hot, hot / n, bpp * px * n / hot / 1e3, cold, cold / n, bpp * px * n / cold / 1e3),
                               flush=True)
             del sets
+        if "corr" in what:
+            levels = [[(a.to(dev), b.to(dev)) for a, b in S.correlation_features(1, h, w, gen)] for _ in range(2)]
+
+            def singles(i):
+                for d in range(2):
+                    for a, b in levels[d]:
+                        cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
+
+            def pairs(i):
+                for (a0, b0), (a1, b1) in zip(levels[0], levels[1]):
+                    cabi.correlation_forward_pair(a0, b0, a1, b1, 4, 1, 4, 1, 1)
+            print("corr     10 single calls %7.1f us | 5 pair calls %7.1f us" % (timed(singles, args.iters), timed(pairs, args.iters)), flush=True)
+            for li, ((a0, b0), (a1, b1)) in enumerate(zip(levels[0], levels[1])):
+                one = timed(lambda i: cabi.correlation_forward(a0, b0, 4, 1, 4, 1, 1), args.iters)
+                two = timed(lambda i: cabi.correlation_forward_pair(a0, b0, a1, b1, 4, 1, 4, 1, 1), args.iters)
+                print("corr     level %d %s: one call %6.1f us, pair %6.1f us" % (li, tuple(a0.shape), one, two), flush=True)
         if "multi" in what or "single" in what:
             ctx = S.context(1, 196, h, w, gen).to(dev)
             filt = S.filters(1, h, w, gen).to(dev)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "vfi_correlation_output_dims": [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i),
                                     ctypes.POINTER(_i)],
     "vfi_correlation_forward": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "vfi_correlation_forward_pair": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "vfi_correlation_forward_f16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "vfi_correlation_backward": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     # glue either side of the ops
@@ -495,6 +496,25 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
     if err != 0:
         raise RuntimeError("CUDA call failed")
     return output
+
+
+def correlation_forward_pair(a1, a2, b1, b2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """(correlation_forward(a1, a2, ...), correlation_forward(b1, b2, ...)) from one launch: float32, equal shapes."""
+    for t in (a1, a2, b1, b2):
+        _dev(t)
+        if tuple(t.shape) != tuple(a1.shape):
+            raise RuntimeError("correlation_forward_pair: the four inputs must have one shape")
+    a1, a2, b1, b2 = (t.contiguous() for t in (a1, a2, b1, b2))
+    b, c, h, w = a1.shape
+    oc, oh, ow = correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2)
+    outa = torch.empty((b, oc, oh, ow), device=a1.device, dtype=torch.float32)
+    outb = torch.empty_like(outa)
+    with torch.cuda.device(_dev(a1)):
+        err = lib().vfi_correlation_forward_pair(_ptr(a1), _ptr(a2), _ptr(outa), _ptr(b1), _ptr(b2), _ptr(outb), b, c, h, w,
+                                                 pad_size, kernel_size, max_displacement, stride1, stride2, _stream(a1))
+    if _finish(err) != 0:
+        raise RuntimeError("correlation_forward_pair: the binding returned %d" % err)
+    return outa, outb
 
 
 def correlation_backward(input1, input2, gradoutput, pad_size, kernel_size, max_displacement, stride1, stride2):

@@ -25,6 +25,10 @@
 
 namespace vfi {
 
+// The tensors of a launch: one call, or two calls of equal shape in one launch (both flow directions of a pyramid level: at
+// the coarse levels a launch is latency, 13-18 us for 1 MB, and two cost what one does).  Images 0 .. per - 1 are item 0's.
+struct CorrItems { const float* in1[2]; const float* in2[2]; float* out[2]; int per; };
+
 #define CORR_CC 8       // channels staged per LDS fill
 #define CORR_CC_ROWS 8   // ... in the small-frame kernel (16 measured the same: its chunk loop is LDS-bound, one workgroup per CU)
 
@@ -36,8 +40,7 @@ __device__ __forceinline__ float padded_at(const float* __restrict__ f, int h, i
 // centred on input pixel (oy + org, ox + org).
 template <int MD, int CORR_TW, int CORR_TH>
 __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
-    int channel, int h, int w, int oh, int ow, int org) {
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     constexpr int LW = CORR_TW + 2 * MD, LH = CORR_TH + 2 * MD;
     constexpr int NI = (LH + CORR_TH - 1) / CORR_TH, NJ = (LW + CORR_TW - 1) / CORR_TW;
@@ -45,7 +48,11 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
 
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int ox = blockIdx.x * CORR_TW + tx, oy = blockIdx.y * CORR_TH + ty;
-    const int b = blockIdx.z;
+    const int item_ = (int)blockIdx.z >= items.per ? 1 : 0;   // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = (int)blockIdx.z - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
     const int64_t plane = (int64_t)h * w;
     const float* f1 = in1 + (int64_t)b * channel * plane;
     const float* f2 = in2 + (int64_t)b * channel * plane;
@@ -127,8 +134,7 @@ __global__ __launch_bounds__(CORR_TW * CORR_TH) void corr_forward_k1(
 // k == 1, strides 1, small frames: tile of 16x4 output pixels, threadIdx.y = displacement row tj.
 template <int MD>
 __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
-    int channel, int h, int w, int oh, int ow, int org) {
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     constexpr int TW = 16, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;
     constexpr int NT = 64 * D, NE = CORR_CC_ROWS * LH * LW;      // threads, staged elements per chunk
@@ -140,7 +146,11 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
     const int tid = tj * 64 + lane;
     const int px = lane & (TW - 1), py = lane >> 4;
     const int ox = blockIdx.x * TW + px, oy = blockIdx.y * TH + py;
-    const int b = blockIdx.z;
+    const int item_ = (int)blockIdx.z >= items.per ? 1 : 0;   // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = (int)blockIdx.z - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
     const int64_t plane = (int64_t)h * w;
     const float* f1 = in1 + (int64_t)b * channel * plane;
     const float* f2 = in2 + (int64_t)b * channel * plane;
@@ -220,8 +230,7 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows(
 // channel order.
 template <int MD>
 __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
-    int channel, int h, int w, int oh, int ow, int org) {
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     constexpr int TW = 32, TH = 4, LW = TW + 2 * MD, LH = TH + 2 * MD;          // LW = 40: 10 aligned 16-byte units
     constexpr int NT = 64 * D;
@@ -238,7 +247,11 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
     const int tid = tj * 64 + lane;
     const int px = 2 * (lane & 15), py = lane >> 4;
     const int ox = blockIdx.x * TW + px, oy = blockIdx.y * TH + py;
-    const int b = blockIdx.z;
+    const int item_ = (int)blockIdx.z >= items.per ? 1 : 0;   // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = (int)blockIdx.z - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
     const int64_t plane = (int64_t)h * w;
     const float* f1 = in1 + (int64_t)b * channel * plane;
     const float* f2 = in2 + (int64_t)b * channel * plane;
@@ -354,8 +367,7 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
 // waves do not fill the chip).  The f32 MFMA runs at the vector units' rate and 72 % of its products fall outside the band.
 template <int MD>
 __global__ __launch_bounds__(1024) void corr_forward_k1_mfma(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
-    int channel, int h, int w, int oh, int ow, int org) {
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org) {
     static_assert(MD == 4, "two 16-wide tiles hold a band of 9 around 16 pixels");
     constexpr int D = 2 * MD + 1;
     constexpr int TW = 64, TH = 4, LW = TW + 16, LH = TH + 2 * MD;              // window: 80 columns (20 units), 12 rows
@@ -368,7 +380,11 @@ __global__ __launch_bounds__(1024) void corr_forward_k1_mfma(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = wave & 3, ry = wave >> 2;                                    // 16-pixel segment and row of the tile
-    const int b = blockIdx.z;
+    const int item_ = (int)blockIdx.z >= items.per ? 1 : 0;   // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = (int)blockIdx.z - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
     const int64_t plane = (int64_t)h * w;
     const float* f1 = in1 + (int64_t)b * channel * plane;
     const float* f2 = in2 + (int64_t)b * channel * plane;
@@ -465,8 +481,7 @@ __global__ __launch_bounds__(1024) void corr_forward_k1_mfma(
 // workgroups for 18x31).  Sequential channel order, as everywhere.
 template <int MD>
 __global__ __launch_bounds__(256) void corr_forward_k1_flat(
-    const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out,
-    int batch, int channel, int h, int w, int oh, int ow, int org) {
+    CorrItems items, int batch, int channel, int h, int w, int oh, int ow, int org) {
     constexpr int D = 2 * MD + 1;
     const int64_t total = (int64_t)batch * D * D * oh * ow;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,7 +489,12 @@ __global__ __launch_bounds__(256) void corr_forward_k1_flat(
     const int ox = (int)(gid % ow);
     const int oy = (int)((gid / ow) % oh);
     const int tc = (int)((gid / ((int64_t)ow * oh)) % (D * D));
-    const int b = (int)(gid / ((int64_t)ow * oh * D * D));
+    const int bz = (int)(gid / ((int64_t)ow * oh * D * D));
+    const int item_ = bz >= items.per ? 1 : 0;              // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = bz - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
     const int y1 = oy + org, x1 = ox + org;
     const int y2 = y1 + tc / D - MD, x2 = x1 + tc % D - MD;
     float acc = 0.0f;
@@ -492,7 +512,7 @@ __global__ __launch_bounds__(256) void corr_forward_k1_flat(
         }
         for (; c < channel; ++c) acc = fmaf(p1[(int64_t)c * plane], p2[(int64_t)c * plane], acc);
     }
-    out[gid] = acc / (float)channel;
+    out[gid - (int64_t)item_ * items.per * D * D * oh * ow] = acc / (float)channel;
 }
 
 // any kernel size / strides: one thread per output element, sequential channel order
@@ -833,54 +853,94 @@ extern "C" int vfi_correlation_output_dims(int h, int w, int pad_size, int kerne
     return VFI_OK;
 }
 
-extern "C" int vfi_correlation_forward(const float* input1, const float* input2, float* output, int batch, int channel,
-                                        int h, int w, int pad_size, int kernel_size, int max_displacement,
-                                        int stride1, int stride2, vfi_stream_t stream) {
+// one call, or two calls of equal shape (nitems == 2) in one launch
+static int correlation_forward_items(const float* const* in1s, const float* const* in2s, float* const* outs, int nitems, int per,
+                                     int channel, int h, int w, int pad_size, int kernel_size, int max_displacement,
+                                     int stride1, int stride2, vfi_stream_t stream) {
     int oc, oh, ow;
-    if (batch <= 0 || channel <= 0 || h <= 0 || w <= 0 || !input1 || !input2 || !output) return VFI_ERR_SHAPE;
+    if (nitems < 1 || nitems > 2 || per <= 0 || channel <= 0 || h <= 0 || w <= 0) return VFI_ERR_SHAPE;
+    for (int i = 0; i < nitems; ++i)
+        if (!in1s[i] || !in2s[i] || !outs[i]) return VFI_ERR_SHAPE;
+    if (nitems == 2 && outs[0] == outs[1]) return VFI_ERR_SHAPE;
     if (vfi_correlation_output_dims(h, w, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow))
         return VFI_ERR_SHAPE;
     if (oh <= 0 || ow <= 0) return VFI_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    const int batch = nitems * per;                          // images of the launch
+    CorrItems items;
+    uintptr_t in_bits = 0, out_bits = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int k = i < nitems ? i : 0;
+        items.in1[i] = in1s[k]; items.in2[i] = in2s[k]; items.out[i] = outs[k];
+        in_bits |= reinterpret_cast<uintptr_t>(in1s[k]) | reinterpret_cast<uintptr_t>(in2s[k]);
+        out_bits |= reinterpret_cast<uintptr_t>(outs[k]);
+    }
+    items.per = per;
     const int kr = (kernel_size - 1) / 2, dr = max_displacement / stride2;
     if (kernel_size == 1 && stride1 == 1 && stride2 == 1 && max_displacement == 4) {
         const int64_t big_tiles = (int64_t)((ow + 31) / 32) * ((oh + 7) / 8) * batch;
         const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
         // 16-byte staging needs rows, planes and bases aligned (plane = h * w floats); the tiled kernel writes a lane's two
         // pixels as one 8-byte store: an output view at an odd element offset of its storage takes the other kernels
-        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
-                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 15) == 0 &&
-                             (reinterpret_cast<uintptr_t>(output) & 7) == 0;
-        if (small_tiles < g_corr_flat_threshold) {
+        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 && (in_bits & 15) == 0 && (out_bits & 7) == 0;
+        if (small_tiles < g_corr_flat_threshold * nitems) {
             const int64_t total = (int64_t)batch * oc * oh * ow;
-            hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,
-                               input2, output, batch, channel, h, w, oh, ow, max_displacement - pad_size);
+            hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, items,
+                               batch, channel, h, w, oh, ow, max_displacement - pad_size);
 #ifdef VFI_DEV
         } else if (g_corr_mfma && aligned) {
             const dim3 grid((ow + 63) / 64, (oh + 3) / 4, batch);
-            hipLaunchKernelGGL(corr_forward_k1_mfma<4>, grid, dim3(1024, 1, 1), 0, st, input1, input2, output,
+            hipLaunchKernelGGL(corr_forward_k1_mfma<4>, grid, dim3(1024, 1, 1), 0, st, items,
                                channel, h, w, oh, ow, max_displacement - pad_size);
 #endif
         } else if (g_corr_rows2 && aligned) {
             const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
-            hipLaunchKernelGGL(corr_forward_k1_rows2<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
+            hipLaunchKernelGGL(corr_forward_k1_rows2<4>, grid, dim3(64, 9, 1), 0, st, items,
                                channel, h, w, oh, ow, max_displacement - pad_size);
-        } else if (big_tiles >= g_corr_big_threshold) {
+        } else if (big_tiles >= g_corr_big_threshold * nitems) {
             const dim3 grid((ow + 31) / 32, (oh + 7) / 8, batch);
-            hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, input1, input2, output,
+            hipLaunchKernelGGL((corr_forward_k1<4, 32, 8>), grid, dim3(32, 8, 1), 0, st, items,
                                channel, h, w, oh, ow, max_displacement - pad_size);
         } else {
             const dim3 grid((ow + 15) / 16, (oh + 3) / 4, batch);
-            hipLaunchKernelGGL(corr_forward_k1_rows<4>, grid, dim3(64, 9, 1), 0, st, input1, input2, output,
+            hipLaunchKernelGGL(corr_forward_k1_rows<4>, grid, dim3(64, 9, 1), 0, st, items,
                                channel, h, w, oh, ow, max_displacement - pad_size);
         }
-    } else {
-        const int64_t total = (int64_t)batch * oc * oh * ow;
-        hipLaunchKernelGGL(corr_forward_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, input1,
-                           input2, output, batch, channel, h, w, oc, oh, ow, pad_size, kr, max_displacement, stride1,
-                           stride2, dr);
+        return launch_status();
     }
-    return launch_status();
+    // any other configuration: the generic kernel, one launch per item
+    for (int i = 0; i < nitems; ++i) {
+        const int64_t total = (int64_t)per * oc * oh * ow;
+        hipLaunchKernelGGL(corr_forward_generic, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in1s[i],
+                           in2s[i], outs[i], per, channel, h, w, oc, oh, ow, pad_size, kr, max_displacement, stride1,
+                           stride2, dr);
+        if (launch_status() != VFI_OK) return VFI_ERR_LAUNCH;
+    }
+    return VFI_OK;
+}
+
+extern "C" int vfi_correlation_forward(const float* input1, const float* input2, float* output, int batch, int channel,
+                                        int h, int w, int pad_size, int kernel_size, int max_displacement,
+                                        int stride1, int stride2, vfi_stream_t stream) {
+    if (batch <= 0 || !input1 || !input2 || !output) return VFI_ERR_SHAPE;
+    return correlation_forward_items(&input1, &input2, &output, 1, batch, channel, h, w, pad_size, kernel_size, max_displacement,
+                                     stride1, stride2, stream);
+}
+
+// Two correlation calls of equal shape in ONE launch -- the same pyramid level of the two flow networks PWCDCNet runs for a
+// frame pair, (I0, I1) and (I1, I0) (networks/DAIN.py:196-202, PWCNet/PWCNet.py:230-300).  Results: the two single calls',
+// bit for bit (the same kernels; which of them runs is decided on the pair's tile count, and every one of them sums the
+// channels in the same order).
+extern "C" int vfi_correlation_forward_pair(const float* input1_a, const float* input2_a, float* output_a,
+                                             const float* input1_b, const float* input2_b, float* output_b,
+                                             int batch, int channel, int h, int w, int pad_size, int kernel_size,
+                                             int max_displacement, int stride1, int stride2, vfi_stream_t stream) {
+    if (batch <= 0) return VFI_ERR_SHAPE;
+    const float* in1s[2] = {input1_a, input1_b};
+    const float* in2s[2] = {input2_a, input2_b};
+    float* outs[2] = {output_a, output_b};
+    return correlation_forward_items(in1s, in2s, outs, 2, batch, channel, h, w, pad_size, kernel_size, max_displacement,
+                                     stride1, stride2, stream);
 }
 
 extern "C" int vfi_correlation_forward_f16(const void* input1, const void* input2, void* output, int batch, int channel,

@@ -153,6 +153,12 @@ def warp_corr(c1, c2, flo, align_corners=True, one_launch=False):
     return cabi.correlation_forward(c1, warp(c2, flo, align_corners), 4, 1, 4, 1, 1)
 
 
+def corr_pair(c1_a, c2_a, c1_b, c2_b):
+    """`self.corr(c1, c2)` of the two flow networks of a frame pair at one pyramid level (PWCNet/PWCNet.py:230, 246, 267, 283,
+    300 for the (I0, I1) network and again for (I1, I0): networks/DAIN.py:196-202) in one launch; returns both cost volumes."""
+    return cabi.correlation_forward_pair(c1_a, c2_a, c1_b, c2_b, 4, 1, 4, 1, 1)
+
+
 def padding_for(height, width):
     """(left, right, top, bottom) of `demo_MiddleBury.py:294-310`: next multiple of 128, or 32 each side."""
     def one(n):
