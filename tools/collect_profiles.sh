@@ -10,8 +10,10 @@
 # 5. (round 3) PMC passes over the north-star gate's kernels: the FilterInterpolation C=3 launch and the three launches
 #    of a FlowProjection call -- EA read requests, WRITE_SIZE, instruction and wait counters (tools/prof_fi.py smooth 3,
 #    tools/bench_proj.py)
+# 6. (round 4) the list form of the projections: kernel trace of tools/bench_r4.py --what projbatch (n = 1, 2, 6 items per launch
+#    triple) and PMC passes over the same driver; the shared-window FilterInterpolation launch: PMC passes over tools/prof_multi.py
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -42,4 +44,20 @@ for ctr in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/gate_fi3_$n -- python3 $R/tools/prof_fi.py smooth 3 > /dev/null 2>&1 || exit 1
 done
 echo gate-pmc-done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/projbatch -- python3 $R/tools/bench_r4.py --what projbatch --flows smooth --iters 30 > $OUT/projbatch_bench.log 2>&1 || exit 1
+for ctr in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"; do
+  n=$(echo $ctr | cut -d' ' -f1)
+  timeout -k 5 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/batch_proj_$n -- python3 $R/tools/bench_r4.py --what projbatch --flows smooth --iters 6 > /dev/null 2>&1 || exit 1
+done
+echo projbatch-done
+for ctr in "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
+  n=$(echo $ctr | cut -d' ' -f1)
+  timeout -k 5 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/multi3_$n -- python3 $R/tools/prof_multi.py smooth 3 > /dev/null 2>&1 || exit 1
+done
+echo multi-pmc-done
 echo collected > $OUT/done

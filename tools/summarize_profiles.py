@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(ROOT, "profiles")
 H, W = 1152, 1984
@@ -136,6 +136,29 @@ if os.path.exists(os.path.join(extras, "f16_corr_pmc.json")):
                 entries.append({"h": H, "w": W, "flow_model": "smooth", "direct": False, "op": op, "kernel": k,
                                 "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": alg,
                                 "ratio": round((rd + wr) / alg, 3), "source": "profiles/%s_f16_corr_pmc.json (EA_RDREQ x 128 B + WRITE_SIZE)" % tag})
+# (round 4) the list form of the projections and the shared-window launch
+if os.path.isdir(os.path.join(src, "projbatch")):
+    by_shape(one("projbatch/**/*kernel_trace.csv"), os.path.join(dst, tag + "_projbatch_kernel_by_shape.csv"))
+    shutil.copy(os.path.join(src, "projbatch_bench.log"), os.path.join(dst, tag + "_projbatch_bench.txt"))
+    batch = {}
+    for d in sorted(glob.glob(os.path.join(src, "batch_proj_*"))):
+        f = one(os.path.join(os.path.basename(d), "**", "*counter_collection.csv"))
+        vals = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "proj_" in r["Kernel_Name"]:
+                # split by launch size: the grid tells how many items a launch carried
+                key = "%s grid_x=%s %s" % (r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", "?"), r["Counter_Name"])
+                vals[key].append(float(r["Counter_Value"]))
+        for k, v in vals.items():
+            batch[k] = sum(v) / len(v)
+    with open(os.path.join(dst, tag + "_projbatch_pmc.json"), "w") as fh:
+        json.dump(batch, fh, indent=1, sort_keys=True)
+    multi = {}
+    for d in sorted(glob.glob(os.path.join(src, "multi3_*"))):
+        for k, v in counters(d, "fi_forward_ori_multi").items():
+            multi[k] = v
+    with open(os.path.join(dst, tag + "_multi3_pmc.json"), "w") as fh:
+        json.dump(multi, fh, indent=1, sort_keys=True)
 with open(os.path.join(dst, "traffic_by_config.json"), "w") as fh:
     json.dump({"entries": entries}, fh, indent=1)
 print(json.dumps(entries, indent=1))

@@ -71,7 +71,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_B64_MIN_BH 34                             // bounding box from which a tile takes the aligned 8-byte tap reads
 #define FI_B64_MIN_BW 92
 #ifdef VFI_DEV
-#define FI_ABL(flags) (((flags) >> 20) & 63)        // development: parts of the lean loop switched off (wrong results, timing only)
+#define FI_ABL(flags) (((flags) >> 20) & 255)       // development: parts of the lean loop switched off or aliased (wrong results, timing only)
 #else
 #define FI_ABL(flags) 0
 #endif
@@ -269,6 +269,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     const int last = c_end - 1;
     const float* pdma = img + (int64_t)c_begin * cs;            // plane the next window is staged from
     float* pout = out + (int64_t)c_begin * cs;                  // plane the next results go to
+    int alias_in = 0, alias_out = 0;                            // (development: abl bits 6 / 7 keep the planes read / written inside 16)
     auto issue = [&](int slot) {
         const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
         float* l = ring + slot * NP + wave_first;
@@ -278,6 +279,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS), 4, goff[k], 0, 0, 0);
         }
         pdma += cs;
+        if ((abl & 64) && (++alias_in & 15) == 0) pdma -= 16 * cs;
     };
 #define FI_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
 #define FI_READ64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
@@ -367,6 +369,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
             if constexpr (p + 2 < FI_PX) reads(std::integral_constant<int, p + 2>{}, I0{});
         });
         pout += cs;
+        if ((abl & 128) && ++alias_out == 16) { alias_out = 1; pout -= 15 * cs; }    // (planes 1 .. 15 after the first lap: the skewed store reaches one plane back)
     };
     // Two pixels, 4-byte reads: the pipeline is skewed by one pixel across the barrier.  In channel c a wave issues pixel 0's
     // reads, multiplies pixel 1 of channel c - 1 (its taps were read before the barrier and wait in registers), issues pixel
@@ -432,6 +435,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         // pixel 1's taps are in registers before the barrier: the slot may be overwritten after it
         arrived_s(qb, std::integral_constant<int, 0>{});
         pout += cs;
+        if ((abl & 128) && ++alias_out == 16) { alias_out = 1; pout -= 15 * cs; }    // (planes 1 .. 15 after the first lap: the skewed store reaches one plane back)
     };
     const bool skew = SKEW && !(abl & 32);
     // prologue: the first D windows
