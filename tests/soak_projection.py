@@ -86,6 +86,23 @@ for it in range(cases):
                 ok = False
                 print("MISMATCH case %d: B=%d H=%d W=%d %s dyadic=%s fillhole=%d depth=%s max|dcount| %g max|dflow| %g"
                       % (it, B, H, W, kind, dyadic, fh, depth, np.abs(c - rc).max(), np.abs(o - r).max()), flush=True)
+    if it % 4 == 0 and kind != "wild":
+        # the list form (round 4): this field, a scaled copy and its negative as ONE call == three single calls, bit for bit
+        items = [gf, (gf * 0.5).contiguous(), (-gf).contiguous()]
+        for depth in (False, True):
+            cn = [torch.full((B, 1, H, W), float("nan"), device=dev) for _ in items]
+            ou = [torch.full((B, 2, H, W), float("nan"), device=dev) for _ in items]
+            assert cabi.flowprojection_forward_batch(items, cn, ou, 1, gw if depth else None) == 0
+            for k, fl in enumerate(items):
+                c1, o1 = torch.empty_like(cn[k]), torch.empty_like(ou[k])
+                if depth:
+                    assert cabi.depthflowprojection_forward(fl, gw, c1, o1, 1) == 0
+                else:
+                    assert cabi.flowprojection_forward(fl, c1, o1, 1) == 0
+                if not (torch.equal(c1, cn[k]) and torch.equal(o1, ou[k])):
+                    ok = False
+                    print("MISMATCH case %d: batched item %d differs from its single call (B=%d H=%d W=%d %s depth=%s)"
+                          % (it, k, B, H, W, kind, depth), flush=True)
     bad += 0 if ok else 1
     if it % 25 == 24:
         print("%d cases, %d with mismatches" % (it + 1, bad), flush=True)
