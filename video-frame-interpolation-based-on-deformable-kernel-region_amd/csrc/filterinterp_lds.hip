@@ -66,7 +66,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FI_RMAX
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
 #endif
-#define FI_KTOP (15 * FI_KS)                        // staged elements per thread and channel, at most
+#define FI_KTOP ((FI_RING_FLOATS / (2 * FI_THREADS)) < 15 * FI_KS ? 12 * FI_KS : 15 * FI_KS)    // staged elements per thread and channel, at most (two ring slots)
 #define FI_XCDS 8
 #define FI_B64_MIN_BH 34                             // bounding box from which a tile takes the aligned 8-byte tap reads
 #define FI_B64_MIN_BW 92
@@ -487,7 +487,10 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
 
 // two 512-thread workgroups per CU (4 waves per SIMD): at most 128 VGPRs
 template <bool BLEND, int MODE>
-__global__ __launch_bounds__(FI_THREADS, 8 / FI_PX) void fi_forward_ori_lds(
+#ifndef FI_WAVES
+#define FI_WAVES (8 / FI_PX)                        // waves per SIMD the kernel must fit (4: two 512-thread workgroups per CU)
+#endif
+__global__ __launch_bounds__(FI_THREADS, FI_WAVES) void fi_forward_ori_lds(
     const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ in3,
     float* __restrict__ out, int channel, int h, int w,
     vfi_strides s1, vfi_strides s2, vfi_strides s3,
@@ -663,7 +666,9 @@ __global__ __launch_bounds__(FI_THREADS, 8 / FI_PX) void fi_forward_ori_lds(
     else if (kmax <= 8 * FI_KS) FI_RUN(8 * FI_KS);
     else if (kmax <= 10 * FI_KS) FI_RUN(10 * FI_KS);
     else if (kmax <= 12 * FI_KS) FI_RUN(12 * FI_KS);
+#if FI_RING_FLOATS >= 2 * 15 * FI_KS * FI_THREADS
     else FI_RUN(15 * FI_KS);
+#endif
 #undef FI_RUN
 }
 
