@@ -327,8 +327,20 @@ def test_no_register_spills_inside_the_counted_vmcnt_pipelines(built):
             pipelined = (any(is_dma(i) for i in b["ins"]) and not prologue_ok) or (b["loop"] in dma_loops)
             if not pipelined or (b["loop"] in dma_loops and b["loop"] not in counted):
                 continue
+            # a straight-line block that stages windows and then waits for EVERYTHING (hand-written vmcnt(0) only: the prologue
+            # of a two-slot ring) cannot be hurt by a spill either
+            own = [re.match(r"s_waitcnt vmcnt\((\d+)\)", i) for i in b["asm"]]
+            own = [int(m.group(1)) for m in own if m]
+            if b["loop"] is None and own and max(own) == 0:
+                continue
             checked += 1
-            spills = [i for i in b["ins"] if i.startswith("scratch_")]
+            ins = b["ins"]
+            if b["loop"] is None:
+                # (straight-line code: a spill OLDER than the block's first staging load retires before it -- vector-memory
+                #  operations complete in issue order -- and leaves every counted wait as written)
+                first = next(k for k, i in enumerate(ins) if is_dma(i))
+                ins = ins[first:]
+            spills = [i for i in ins if i.startswith("scratch_")]
             assert not spills, "%s %s: %d scratch operations inside an LDS-DMA pipeline: %s" % (
                 name, b["label"], len(spills), spills[:3])
     assert checked >= 60                    # every K instantiation of every staged kernel was looked at

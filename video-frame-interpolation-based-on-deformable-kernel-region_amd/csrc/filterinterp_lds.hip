@@ -61,7 +61,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FI_KS (FI_PX / 2)                           // staged elements per thread scale with the pixels per thread
 #define FI_HDR 16                                   // floats at the head of the LDS array (bounding box)
 #ifndef FI_RING_FLOATS
-#define FI_RING_FLOATS 15984                        // LDS ring: 16000 floats = 64,000 B with the header
+#define FI_RING_FLOATS 20464                        // LDS ring: 20480 floats = 81,920 B with the header: two workgroups = a CU's 160 KB (round 4; 64,000 B before)
 #endif
 #ifndef FI_RMAX
 #define FI_RMAX 5                                   // ring slots, at most (4 windows in flight)
@@ -227,12 +227,18 @@ __device__ __forceinline__ void fi_run_channels(const float* __restrict__ img, f
 //  * tap reads are asm with two hand-placed lgkmcnt waits per channel instead of fourteen, and the second pixel's first
 //    reads are in flight while the first pixel is multiplied;
 //  * results leave through buffer stores whose offset is out of range for an invalid pixel: no exec-mask juggling.
-template <int K, bool B64>
+//  * DMA16 (built in round 3, on since round 4): a window whose columns all lie inside the image, in a tensor whose rows are
+//    16-byte aligned, starts on a multiple of four columns and is staged in 16-byte units (K counts units per thread): a
+//    quarter of the DMA instructions.  Same window contents, same tap reads, same bits.  With the 64,000-byte ring of round 3
+//    the coarser units cost two ring slots and the launch 4-8 %; with 81,920 bytes (K = 2 units: four slots) it gains
+//    1.5-3 % on the smooth field and 5 % on the quarter field (tools/fi_variant_check.py --flags 0x8,0x10000008).
+template <int K, bool B64, bool DMA16 = false>
 __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ img, float* __restrict__ out, int64_t cs,
                                                      int c_begin, int c_end, int tid, const FiWindow& win,
                                                      const FiPixel (&px)[FI_PX], float* __restrict__ ring, int abl) {
     typedef float v2f __attribute__((ext_vector_type(2)));
-    constexpr int NP = K * FI_THREADS;
+    constexpr int EPT = DMA16 ? 4 : 1;                      // floats per staged element
+    constexpr int NP = K * FI_THREADS * EPT;
     constexpr int R = (FI_RING_FLOATS / NP) < FI_RMAX ? (FI_RING_FLOATS / NP) : FI_RMAX;
     constexpr int D = R - 1;
     static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
@@ -241,10 +247,11 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     unsigned goff[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int e = tid + k * FI_THREADS;
+        const int e = (tid + k * FI_THREADS) * EPT;
         const int r = fi_row_of(e, inv_pitch32);
         const int col = e - r * win.pitch;
-        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + clampi(win.bx0 + col, 0, win.w - 1));
+        // (DMA16: bx0 is a multiple of 4 and bx0 .. bx0 + bw - 1 lie inside the image, whose width is a multiple of 4)
+        const unsigned off = 4u * (unsigned)(clampi(win.by0 + r, 0, win.h - 1) * win.hs + (DMA16 ? win.bx0 + col : clampi(win.bx0 + col, 0, win.w - 1)));
         goff[k] = (col < win.bw && r < win.bh) ? off : 0x80000000u;
     }
     const int plane_bytes = 4 * ((win.h - 1) * win.hs + win.w);
@@ -272,11 +279,11 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     int alias_in = 0, alias_out = 0;                            // (development: abl bits 6 / 7 keep the planes read / written inside 16)
     auto issue = [&](int slot) {
         const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
-        float* l = ring + slot * NP + wave_first;
+        float* l = ring + slot * NP + wave_first * EPT;
         if (!(abl & 2)) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS), 4, goff[k], 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS * EPT), 4 * EPT, goff[k], 0, 0, 0);
         }
         pdma += cs;
         if ((abl & 64) && (++alias_in & 15) == 0) pdma -= 16 * cs;
@@ -375,7 +382,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     // reads, multiplies pixel 1 of channel c - 1 (its taps were read before the barrier and wait in registers), issues pixel
     // 1's reads, multiplies pixel 0, and waits for pixel 1's taps: every LDS read is in flight under arithmetic of the same
     // wave, none is waited for with nothing to do (the plain order exposes the first reads after each barrier).
-    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 10 * FI_KS;     // (4-byte reads; with 8-byte reads -- 24 more registers in flight -- it measured 30 % slower; the two largest ring geometries have no registers to spare)
+    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 8 * FI_KS;      // (4-byte reads; with 8-byte reads -- 24 more registers in flight -- it measured 30 % slower; the three largest ring geometries have no registers to spare: beside the 16-byte-staging instances the K = 10 loop reloaded a register pair inside its counted pipeline)
     constexpr int NQS = B64 ? 12 : 8;                        // register pairs per pixel
     v2f qa[NQS], qb[NQS];
     auto rd_all = [&](v2f (&d)[NQS], int p, unsigned so) {
@@ -607,10 +614,15 @@ __global__ __launch_bounds__(FI_THREADS, FI_WAVES) void fi_forward_ori_lds(
     constexpr bool lean = !BLEND && MODE != 1;
     // (the 8-byte layout's pitch is = 32 mod 64 floats: a window that needs more than 10 x 512 elements with it keeps the
     //  4-byte reads and their tighter pitch -- the two largest ring geometries are compiled for those only)
-    const int bw64 = any_valid ? box[2] - (box[0] & ~1) + 1 : 0;
+    // 16-byte staging (flags bit 28; bit 29, set by the host: width, strides and base of input1 are multiples of 16 bytes):
+    // every column of the window inside the image, rows of the tensor 16-byte aligned; the
+    // window then starts on a multiple of four columns (which is even: the 8-byte reads' parity rule holds too)
+    const bool can16 = lean && MODE != 1 && (flags & (3 << 28)) == (3 << 28) && any_valid && box[0] >= 0 && box[2] < w;
+    const int lo = can16 ? (box[0] & ~3) : box[0];
+    const int bw64 = any_valid ? box[2] - (lo & ~1) + 1 : 0;
     const bool fits64 = ((((bw64 + 31) >> 6) << 6) + 32) * raw_bh <= 10 * FI_KS * FI_THREADS;
     const bool use64 = lean && (MODE == 2 || (MODE == 0 && fits64 && (raw_bh >= FI_B64_MIN_BH || raw_bw >= FI_B64_MIN_BW)));
-    const int bx0 = (use64 && any_valid) ? (box[0] & ~1) : box[0], by0 = box[1];       // 8-byte reads: window columns keep the image's parity
+    const int bx0 = (use64 && any_valid) ? (lo & ~1) : lo, by0 = box[1];       // 8-byte reads: window columns keep the image's parity
     const int bw = any_valid ? box[2] - bx0 + 1 : 0;
     const int bh = raw_bh;
     // LDS row pitch: a multiple of the 32 banks; 8-byte reads see 64 banks: = 32 mod 64
@@ -657,6 +669,17 @@ __global__ __launch_bounds__(FI_THREADS, FI_WAVES) void fi_forward_ori_lds(
     } else if constexpr (lean) fi_run_channels_lean<K, MODE == 2>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); else \
                   fi_run_channels<K, BLEND>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, \
                                      min(((flags >> 8) & 255) ? ((flags >> 8) & 255) : FI_RMAX, FI_RING_FLOATS / ((K) * FI_THREADS)), flags, bl)
+    if constexpr (lean && MODE != 1) {
+        // (units of four floats: two or three per thread cover the windows of smooth fields; larger ones stay on 4-byte staging)
+        const int k16 = (n + 4 * FI_THREADS - 1) / (4 * FI_THREADS);
+        if (can16 && k16 <= 3) {
+#define FI_RUN16(K) { if (use64) fi_run_channels_lean<K, true, true>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); \
+                      else fi_run_channels_lean<K, false, true>(img, dst, s1.c, c_begin, c_end, tid, win, px, ring, FI_ABL(flags)); }
+            if (k16 <= 1) FI_RUN16(1) else if (k16 == 2) FI_RUN16(2) else FI_RUN16(3)
+#undef FI_RUN16
+            return;
+        }
+    }
     if (kmax <= 2 * FI_KS) FI_RUN(2 * FI_KS);
     else if (kmax <= 3 * FI_KS) FI_RUN(3 * FI_KS);
     else if (kmax <= 4 * FI_KS) FI_RUN(4 * FI_KS);
@@ -672,6 +695,19 @@ __global__ __launch_bounds__(FI_THREADS, FI_WAVES) void fi_forward_ori_lds(
 #undef FI_RUN
 }
 
+// (explicit: with the 16-byte flavours added, hipcc 7.2 silently left the host stubs of the implicitly instantiated modes 0
+//  and 3 of a development build undefined)
+#define FI_INSTANCE(B, M) template __global__ void fi_forward_ori_lds<B, M>(const float* __restrict__, const float* __restrict__, \
+    const float* __restrict__, float* __restrict__, int, int, int, vfi_strides, vfi_strides, vfi_strides, int, int, int, int, int, int, FiBlend)
+FI_INSTANCE(true, 0);
+FI_INSTANCE(false, 0);
+#ifdef VFI_DEV
+FI_INSTANCE(false, 1);
+FI_INSTANCE(false, 2);
+FI_INSTANCE(false, 3);
+#endif
+#undef FI_INSTANCE
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -679,9 +715,10 @@ using namespace vfi;
 // Kernel flags: bit 0 issue the next DMA before / after the compute phase (plain loop); bit 1 XCD-contiguous bands of tiles;
 // bits 16-17 channel loop (development builds: 1 plain, 2 / 3 lean with 8- / 4-byte tap reads everywhere); bits 20-25 parts of the lean loop
 // switched off (development builds, timing only);
+// bit 28 16-byte staging where a window allows it (bit 29 is set by the host: input1's rows and planes 16-byte aligned);
 // bits 2-3 log2 of the tiles per XCD group (default 2: four horizontally consecutive tiles on one XCD, see the
 // kernel); bits 4-5 two-dimensional groups; bits 8.. ring depth.  g_fi_groups: channel groups, 0 = chosen below.
-#define FI_DEFAULT_FLAGS 8
+#define FI_DEFAULT_FLAGS (8 | (1 << 28))            // four tiles per XCD group; 16-byte staging where a window allows it
 VFI_KNOB(int, g_fi_flags, FI_DEFAULT_FLAGS);
 VFI_KNOB(int, g_fi_groups, 0);
 #ifdef VFI_DEV
@@ -715,12 +752,14 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
         grid_x = ((ngroups + FI_XCDS - 1) / FI_XCDS) * FI_XCDS * GW * GH;
     }
     const dim3 grid((unsigned)grid_x, (unsigned)groups, 1);
+    const int aligned16 = !(w & 3) && !(s1.h & 3) && !(s1.c & 3) && !(s1.b & 3) && !((uintptr_t)input1 & 15);
+    const int kflags = g_fi_flags | (aligned16 << 29);
     if (blend.out)
         hipLaunchKernelGGL((fi_forward_ori_lds<true, 0>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
-                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, kflags, blend);
 #ifdef VFI_DEV
 #define FI_DEV_MODE(M) hipLaunchKernelGGL((fi_forward_ori_lds<false, M>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2, \
-                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend)
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, kflags, blend)
     else if (((g_fi_flags >> 16) & 3) == 1) FI_DEV_MODE(1);   // the plain channel loop
     else if (((g_fi_flags >> 16) & 3) == 2) FI_DEV_MODE(2);   // the lean loop with 8-byte tap reads
     else if (((g_fi_flags >> 16) & 3) == 3) FI_DEV_MODE(3);   // the lean loop with 4-byte tap reads only
@@ -728,7 +767,7 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
 #endif
     else
         hipLaunchKernelGGL((fi_forward_ori_lds<false, 0>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
-                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, g_fi_flags, blend);
+                           input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, kflags, blend);
     return launch_status();
 }
 
