@@ -10,9 +10,9 @@ Workloads
       demo_MiddleBury.py:294-310), i.e. exactly the native calls networks/DAIN_slowmotion.py:147-183 and
       PWCNet/PWCNet.py:230-300 make for it:
           10 x correlation forward   (5 pyramid levels x 2 directions; pad=4,k=1,md=4,s1=s2=1)
-           6 x DepthFlowProjection   (2 directions x t in {0.25,0.5,0.75}; fillhole=1) -- `FlowProject(list, depth)` once
-                                     per direction (networks/DAIN_slowmotion.py:156-159, 301-307): the list form of the
-                                     library projects a direction's three flows in one call
+           6 x DepthFlowProjection   (2 directions x t in {0.25,0.5,0.75}; fillhole=1) -- the networks' two
+                                     `FlowProject(list, depth)` calls back to back (networks/DAIN_slowmotion.py:156-159,
+                                     301-307) as ONE call of the library's list form (fused.FlowProject_directions)
            6 x FilterInterpolation   on the 196-channel context tensor
            6 x FilterInterpolation   on the 3-channel frame
       in the reference's order (all correlations, FlowProject of both directions, then per time offset the two context
@@ -301,15 +301,19 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
         err = fi_call(img, flow, filt, out, direct=args.direct)
         assert err == 0, err
 
+    flat_flows, flat_counts, flat_projs = wl.flows[0] + wl.flows[1], wl.counts[0] + wl.counts[1], wl.projs[0] + wl.projs[1]
+    flat_depth = [wl.depth[0]] * len(TIMES) + [wl.depth[1]] * len(TIMES)
+
     def step(i, record=False):
         # the reference's order (networks/DAIN_slowmotion.py:147-171): both flow networks (their correlations), FlowProject
         # of both directions for every time offset, then per time offset FilterInterpolate_ctx and FilterInterpolate
         for d in range(2):
             for a, b in wl.corr[d]:
                 cabi.correlation_forward(a, b, 4, 1, 4, 1, 1)
-        for d in range(2):                                  # FlowProject(cur_offset_outputs[d], depth_inv[d])
-            err = cabi.flowprojection_forward_batch(wl.flows[d], wl.counts[d], wl.projs[d], 1, wl.depth[d])
-            assert err == 0, err
+        # [FlowProject(cur_offset_outputs[0], depth_inv[0]), FlowProject(cur_offset_outputs[1], depth_inv[1])]
+        # (networks/DAIN_slowmotion.py:156-159): the two lists back to back = one library call (fused.FlowProject_directions)
+        err = cabi.flowprojection_forward_batch(flat_flows, flat_counts, flat_projs, 1, flat_depth)
+        assert err == 0, err
         for ti in range(len(TIMES)):
             for d in range(2):
                 if record:
@@ -376,7 +380,7 @@ def run_slowmo(args, torch, cabi, runner, S, dev, rank, world):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 arithmetic, f16 storage" if half else "f32", "data": "synthetic",
         "config": {"workload": "DAIN_slowmotion x4 hot path, one %dx%d pair padded to %dx%d per step per GPU: "
-                               "10 correlation(pad4,k1,md4) + 6 DepthFlowProjection(fillhole; FlowProject(list) once per direction) + "
+                               "10 correlation(pad4,k1,md4) + 6 DepthFlowProjection(fillhole; both FlowProject lists as one call) + "
                                "6 FilterInterpolation(C=196) + 6 FilterInterpolation(C=3); 3 frames/step"
                                % (args.height, args.width, h, w),
                    "flow_model": args.flow_model, "filter_size": 4, "batch": 1, "storage": args.storage,
