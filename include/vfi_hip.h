@@ -67,8 +67,10 @@ int vfi_filterinterp_backward_ori(const float* input1, const float* input2, cons
 /* The same forward for SEVERAL flows over one image and one filter: outputs[t] = the function above with
  * input2 = flows[t], t < nflows (bit for bit).  This is what DAIN_slowmotion does per direction: FilterInterpolate_ctx
  * (networks/DAIN_slowmotion.py:167-183, 311-317) warps the same context tensor with the same filter once per time
- * offset.  With filter_channels == 16 one launch stages ONE window per tile and channel for up to three flows (a third
- * of the image traffic per output; more flows go in groups of three and two); other filter sizes are single launches.
+ * offset.  With filter_channels == 16 one launch stages ONE window per tile and channel for two flows (half the image
+ * traffic per output; more flows go in pairs, a last odd one alone: the three time offsets of DAIN_slowmotion x4 = one
+ * two-flow launch + one single-flow launch -- measured faster than a three-flow launch, whose union window outgrows the
+ * LDS ring); other filter sizes are single launches.
  * flows / outputs: HOST arrays of nflows device pointers; every flow has strides s2, every output s1. */
 int vfi_filterinterp_forward_ori_multi(const float* input1, const float* const* flows, const float* input3,
                                        float* const* outputs, int nflows,

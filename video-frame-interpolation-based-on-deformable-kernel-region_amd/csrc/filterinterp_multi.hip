@@ -44,8 +44,9 @@ namespace vfi {
 #define FM_XCDS 8
 #define FM_MAXT 3                                   // flows per launch (4 spills inside the channel loop at 128 registers)
 #ifndef FM_GROUP
-#define FM_GROUP 3                                  // flows per launch the host forms groups of
-#endif
+#define FM_GROUP 2                                  // flows per launch the host forms groups of (round 4: three flows go as 2 + 1 --
+#endif                                              // 2.78 against 3.01 ms at 1080p, C = 196: the union window of three time offsets
+                                                    // costs the three-flow launch its ring depth; that launch stays in development builds)
 
 typedef __attribute__((address_space(3))) void* fm_lptr_t;
 
@@ -621,7 +622,7 @@ extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const flo
     }
     // the shared-window kernel: fs == 4, 2 or 3 flows, in-plane byte offsets within 32 bits; anything else is the
     // single-flow entry point once per flow (same results)
-    const bool staged = filter_channels == 16 && nflows >= 2 && nflows <= FM_MAXT && (int64_t)h * s1.h * 4 <= INT_MAX &&
+    const bool staged = filter_channels == 16 && nflows >= 2 && nflows <= g_fm_group && (int64_t)h * s1.h * 4 <= INT_MAX &&
                         s2.c >= 0 && s3.c >= 0 && (s2.c + (int64_t)h * s2.h) * 4 <= INT_MAX && (15 * s3.c + (int64_t)h * s3.h) * 4 <= INT_MAX;
     if (!staged) {
         for (int t = 0; t < nflows; ++t) {
@@ -645,8 +646,10 @@ extern "C" int vfi_filterinterp_forward_ori_multi(const float* input1, const flo
     const dim3 grid((unsigned)(per_xcd * FM_XCDS), (unsigned)groups, 1), block(FM_THREADS, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     switch (nflows) {
-    case 2: hipLaunchKernelGGL(fi_forward_ori_multi<2>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
-    default: hipLaunchKernelGGL(fi_forward_ori_multi<3>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
+#ifdef VFI_DEV
+    case 3: hipLaunchKernelGGL(fi_forward_ori_multi<3>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
+#endif
+    default: hipLaunchKernelGGL(fi_forward_ori_multi<2>, grid, block, 0, st, input1, ptr, input3, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, ch_per_group, g_fm_kpair); break;
     }
     return launch_status();
 }
