@@ -61,6 +61,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 struct FmPtrs { const float* flow[FM_MAXT]; float* out[FM_MAXT]; };
 
+#ifndef FM_DEEP
+#define FM_DEEP 0           // 1: (two flows) a whole evaluation's tap reads per register set, 16 LDS reads in flight -- measured 3.5 % SLOWER
+#endif                      //    than half evaluations (1.66 against 1.60 ms per two-flow launch at 1080p, C = 196): kept as a build switch
 #ifndef FM_ABL
 #define FM_ABL 0            // development: parts of the paired loop switched off (wrong results, timing only): 1 stores, 2 staging, 4 tap reads
 #endif
@@ -171,9 +174,57 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d1) : "v"(addr), "n"((r) * PITCH8 + 8)); } while (0)
     auto compute = [&](int slot) {
         const unsigned so = (unsigned)(slot * (NP * 4));
-        // Two register sets of four pairs ping-pong at half-evaluation grain: while the top sums of evaluation e are formed from
-        // rows 0-1 (set 0), rows 2-3 (set 1) are in flight; while the bottom sums are formed, rows 0-1 of evaluation e + 1 are.
-        // (Whole evaluations in flight -- 2 x 8 pairs -- do not fit beside 2 x 3 evaluations' state at 128 registers.)
+        // Tap reads ping-pong between two register sets.  Three flows (development builds): half an evaluation per set -- while the
+        // top sums of evaluation e are formed from rows 0-1 (set 0), rows 2-3 (set 1) are in flight, and so on; whole
+        // evaluations in flight do not fit beside 2 x 3 evaluations' state at 128 registers.  Two flows could hold a whole
+        // evaluation per set (FM_DEEP: 16 LDS reads in flight, what the 4-bit lgkmcnt can count) -- measured slower, off.
+        constexpr bool DEEP = NT < 3 && FM_DEEP;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I4 = std::integral_constant<int, 4>;
+        auto finish = [&](auto E, const v2f& top, const v2f& bot) {
+            constexpr int e = decltype(E)::value, t = e / FM_PX, p = e % FM_PX;
+            float val = W[e][0] * top.x;                    // (blend4, its weights formed above)
+            val = fmaf(W[e][1], top.y, val);
+            val = fmaf(W[e][2], bot.x, val);
+            val = fmaf(W[e][3], bot.y, val);
+            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
+            // an invalid evaluation's store is dropped by the range check.  (The select is formed here, from a validity mask
+            // the compiler keeps in scalar registers: loop-invariant offsets per evaluation instead of per pixel cost registers.)
+            unsigned po = pix4[p];
+            asm volatile("" : "+v"(po));
+            if (!(FM_ABL & 1) || val == 123456.789f)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
+        };
+        if constexpr (DEEP) {
+            v2f q[2][8];
+            auto reads_all = [&](auto E) {
+                constexpr int e = decltype(E)::value;
+                v2f (&d)[8] = q[e & 1];
+                const unsigned a = lb[e] + so;
+                if (FM_ABL & 4) { for (int i = 0; i < 8; ++i) d[i] = v2f{__uint_as_float(a), 1.0f}; return; }
+                FM_READ_ROW(d[0], d[1], a, 0); FM_READ_ROW(d[2], d[3], a, 1);
+                FM_READ_ROW(d[4], d[5], a, 2); FM_READ_ROW(d[6], d[7], a, 3);
+            };
+            reads_all(I0{}); reads_all(I1{});
+            static_for<0, NE>([&](auto E) {
+                constexpr int e = decltype(E)::value, p = e % FM_PX;
+                v2f (&d)[8] = q[e & 1];
+                // (LDS reads return in order: with the next evaluation's eight behind them, this one's are back at lgkmcnt(8))
+                asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]),
+                                                        "+v"(d[6]), "+v"(d[7]) : "n"(e + 1 < NE ? 8 : 0));
+                v2f top = d[0] * F[p][0];
+                top = __builtin_elementwise_fma(d[1], F[p][1], top);
+                top = __builtin_elementwise_fma(d[2], F[p][2], top);
+                top = __builtin_elementwise_fma(d[3], F[p][3], top);
+                v2f bot = d[4] * F[p][4];
+                bot = __builtin_elementwise_fma(d[5], F[p][5], bot);
+                bot = __builtin_elementwise_fma(d[6], F[p][6], bot);
+                bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
+                if constexpr (e + 2 < NE) reads_all(std::integral_constant<int, e + 2>{});
+                finish(E, top, bot);
+            });
+        } else {
         v2f q[2][4];
         unsigned adr[2];
         auto reads = [&](auto E, auto H) {                   // rows 2h, 2h + 1 of evaluation e into set h
@@ -188,12 +239,9 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         auto landed = [&](v2f (&d)[4], auto LATER) {         // all but the `later` youngest LDS reads are back
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(decltype(LATER)::value));
         };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I4 = std::integral_constant<int, 4>;
         reads(I0{}, I0{}); reads(I0{}, I1{});
         static_for<0, NE>([&](auto E) {
-            constexpr int e = decltype(E)::value, t = e / FM_PX, p = e % FM_PX;
+            constexpr int e = decltype(E)::value, p = e % FM_PX;
             // d[2r] = columns (0, 2), d[2r + 1] = columns (1, 3) of row r: the sums of fi4_pixel, two quadrants per instruction
             landed(q[0], I4{});
             v2f top = q[0][0] * F[p][0];
@@ -207,18 +255,9 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
             bot = __builtin_elementwise_fma(q[1][2], F[p][6], bot);
             bot = __builtin_elementwise_fma(q[1][3], F[p][7], bot);
             if constexpr (e + 1 < NE) reads(std::integral_constant<int, e + 1>{}, I1{});
-            float val = W[e][0] * top.x;                    // (blend4, its weights formed above)
-            val = fmaf(W[e][1], top.y, val);
-            val = fmaf(W[e][2], bot.x, val);
-            val = fmaf(W[e][3], bot.y, val);
-            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)(ptr.out[t] + oofs), 0, plane_bytes, 0x00020000);
-            // an invalid evaluation's store is dropped by the range check.  (The select is formed here, from a validity mask
-            // the compiler keeps in scalar registers: six loop-invariant offsets instead of two cost registers that spill.)
-            unsigned po = pix4[p];
-            asm volatile("" : "+v"(po));
-            if (!(FM_ABL & 1) || val == 123456.789f)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, px[p].valid[t] ? po : 0x80000000u, 0, 0);
+            finish(E, top, bot);
         });
+        }
         oofs += cs;
     };
 #undef FM_READ_ROW
