@@ -333,3 +333,35 @@ def test_double_tensors_are_refused_like_the_reference_wrappers_would(torch_mod,
         cabi.filterinterp_forward_ori(img, flow, filt, out)
     with pytest.raises(RuntimeError, match="float32"):
         cabi.flowprojection_forward_batch([flow], [torch.zeros((1, 1, 16, 64), device="cuda:0")], [torch.zeros_like(flow)], 1)
+
+
+@pytest.mark.parametrize("model", ["smooth", "zero", "wild"])
+def test_filterinterp_channel_planes_farther_apart_than_a_descriptor_spans(torch_mod, cabi, oracle, model):
+    """The 16-byte-staging loop addresses all planes of a tensor through ONE buffer descriptor and a scalar offset per plane; a
+    descriptor spans 2^31 - 1 bytes, so on tensors larger than that (4K x 196 channels: 6.9 GB) the base moves up every few
+    planes.  Small planes 600 MB apart (a view with a huge channel stride) cross that boundary twice in nine channels without
+    a 4K-sized oracle run: bit-exact with the oracle, nothing written between the planes' neighbours."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    C, H, W = 9, 96, 256
+    cs = 150_000_000                                      # floats: 600 MB between planes (a multiple of four: rows stay 16-byte aligned)
+    img = rng.standard_normal((1, C, H, W)).astype(f32)
+    filt = rng.random((1, 16, H, W), dtype=f32)
+    flow = {"smooth": smooth_flow(rng, 1, H, W, 3.0), "zero": np.zeros((1, 2, H, W), f32),
+            "wild": (rng.standard_normal((1, 2, H, W)) * 40.0).astype(f32)}[model]
+    n = (C - 1) * cs + H * W
+    src = torch.empty(n + 3 * W, device="cuda:0")
+    dst = torch.empty(n + 3 * W, device="cuda:0")
+    gin = torch.as_strided(src, (1, C, H, W), (n, cs, W, 1), 2 * W)
+    gout = torch.as_strided(dst, (1, C, H, W), (n, cs, W, 1), 2 * W)
+    guard = torch.as_strided(dst, (C, 2, W), (cs, H * W + W, 1), W)          # the row just before and the row just after every plane
+    gin.copy_(gpu(torch, img))
+    gout.fill_(float("nan"))
+    guard.fill_(-7.0)
+    assert cabi.filterinterp_forward_ori(gin, gpu(torch, flow), gpu(torch, filt), gout) == 0
+    ref = oracle.filterinterp_ori_fwd(img, flow, filt, fmad=1)
+    assert np.array_equal(cpu(gout.contiguous()), ref)
+    g = cpu(guard.contiguous())
+    assert np.all(g == -7.0)
+    del src, dst
+    torch.cuda.empty_cache()

@@ -277,14 +277,47 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     const float* pdma = img + (int64_t)c_begin * cs;            // plane the next window is staged from
     float* pout = out + (int64_t)c_begin * cs;                  // plane the next results go to
     int alias_in = 0, alias_out = 0;                            // (development: abl bits 6 / 7 keep the planes read / written inside 16)
+    // 16-byte-staging instances: ONE descriptor per tensor, the plane in the instruction's scalar offset -- one scalar add per
+    // channel and tensor instead of a 64-bit pointer add and a descriptor rebuild (a fifth of the loop's scalar instructions;
+    // 2 % of the C=196 launch).  The descriptor spans 2^31 - 1 bytes from its base; when the next plane would end beyond that
+    // the base moves up to the current plane (1080p: never; 4K: every 64th channel).  The range check compares the vector
+    // offset with num_records - soffset: a lane whose offset is 0x80000000 is dropped whatever the plane.  (Host: bit 29
+    // promises 4 * cs + plane_bytes < 2^31.)
+    constexpr bool ONE = DMA16;
+    auto din = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, 0x7fffffff, 0x00020000);
+    auto dout = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, 0x7fffffff, 0x00020000);
+    const int cs4 = (int)(cs * 4);
+    const int soff_max = 0x7fffffff - plane_bytes - cs4;      // largest scalar offset whose successor plane is still in range
+    int sin = 0, sout = 0;
+    auto next_in = [&]() {
+        if (sin > soff_max) {
+            pdma = (const float*)((const char*)pdma + sin);
+            din = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, 0x7fffffff, 0x00020000);
+            sin = 0;
+        }
+        sin += cs4;
+        if ((abl & 64) && (++alias_in & 15) == 0) sin -= 16 * cs4;
+    };
+    auto next_out = [&]() {                                    // (the skewed loop still stores to the plane before: offset sout - cs4 >= 0)
+        if (sout > soff_max) {
+            pout = (float*)((char*)pout + sout);
+            dout = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, 0x7fffffff, 0x00020000);
+            sout = 0;
+        }
+        sout += cs4;
+        if ((abl & 128) && ++alias_out == 16) { alias_out = 1; sout -= 15 * cs4; }
+    };
     auto issue = [&](int slot) {
         const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
         float* l = ring + slot * NP + wave_first * EPT;
         if (!(abl & 2)) {
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS * EPT), 4 * EPT, goff[k], 0, 0, 0);
+            for (int k = 0; k < K; ++k) {
+                if constexpr (ONE) __builtin_amdgcn_raw_ptr_buffer_load_lds(din, (fi_lptr_t)(l + k * FI_THREADS * EPT), 4 * EPT, goff[k], sin, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(plane, (fi_lptr_t)(l + k * FI_THREADS * EPT), 4 * EPT, goff[k], 0, 0, 0);
+            }
         }
+        if constexpr (ONE) { next_in(); return; }
         pdma += cs;
         if ((abl & 64) && (++alias_in & 15) == 0) pdma -= 16 * cs;
     };
@@ -362,7 +395,10 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
                 bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
                 val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
             }
-            if (!(abl & 1) || val == 123456.789f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+            if (!(abl & 1) || val == 123456.789f) {
+                if constexpr (ONE) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), dout, soff[p], sout, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+            }
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -375,6 +411,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
             if constexpr (p + 1 < FI_PX) reads(std::integral_constant<int, p + 1>{}, I1{});
             if constexpr (p + 2 < FI_PX) reads(std::integral_constant<int, p + 2>{}, I0{});
         });
+        if constexpr (ONE) { next_out(); return; }
         pout += cs;
         if ((abl & 128) && ++alias_out == 16) { alias_out = 1; pout -= 15 * cs; }    // (planes 1 .. 15 after the first lap: the skewed store reaches one plane back)
     };
@@ -427,8 +464,12 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
             bot = __builtin_elementwise_fma(d[7], F[p][7], bot);
             val = blend4(px[p].alpha, px[p].beta, top.x, top.y, bot.x, bot.y);
         }
-        const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)plane_ptr, 0, plane_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+        if constexpr (ONE) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), dout, soff[p], sout - (p ? cs4 : 0), 0);
+        } else {
+            const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)plane_ptr, 0, plane_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
+        }
     };
     auto compute_skewed = [&](int slot, bool first) {
         const unsigned so = (unsigned)(slot * (NP * 4));
@@ -441,6 +482,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         fma_store(qa, 0, pout);
         // pixel 1's taps are in registers before the barrier: the slot may be overwritten after it
         arrived_s(qb, std::integral_constant<int, 0>{});
+        if constexpr (ONE) { next_out(); return; }
         pout += cs;
         if ((abl & 128) && ++alias_out == 16) { alias_out = 1; pout -= 15 * cs; }    // (planes 1 .. 15 after the first lap: the skewed store reaches one plane back)
     };
@@ -752,7 +794,9 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
         grid_x = ((ngroups + FI_XCDS - 1) / FI_XCDS) * FI_XCDS * GW * GH;
     }
     const dim3 grid((unsigned)grid_x, (unsigned)groups, 1);
-    const int aligned16 = !(w & 3) && !(s1.h & 3) && !(s1.c & 3) && !(s1.b & 3) && !((uintptr_t)input1 & 15);
+    // (16-byte staging: rows of input1 on 16-byte boundaries; its single-descriptor addressing: two planes within 2^31 bytes)
+    const int aligned16 = !(w & 3) && !(s1.h & 3) && !(s1.c & 3) && !(s1.b & 3) && !((uintptr_t)input1 & 15) &&
+                          s1.c > 0 && 4 * s1.c + 4 * ((int64_t)(h - 1) * s1.h + w) < 0x7fffffffLL;
     const int kflags = g_fi_flags | (aligned16 << 29);
     if (blend.out)
         hipLaunchKernelGGL((fi_forward_ori_lds<true, 0>), grid, dim3(FI_THREADS, 1, 1), 0, (hipStream_t)stream, input1, input2,
