@@ -828,7 +828,11 @@ def test_separableconv_and_flow(torch_mod, cabi, oracle, fs):
                                                    # (aligned rows, >= 64 tiles), one-pixel tiled (unaligned rows),
                                                    # big tiles (unaligned, >= 256 of them); the small ones above are flat
                                                    (6, 32, 128, 4, 1, 4, 1, 1), (19, 41, 256, 4, 1, 4, 1, 1),
-                                                   (5, 33, 130, 4, 1, 4, 1, 1), (3, 136, 514, 4, 1, 4, 1, 1)])
+                                                   (5, 33, 130, 4, 1, 4, 1, 1), (3, 136, 514, 4, 1, 4, 1, 1),
+                                                   # four pixels per lane, three displacement rows per workgroup (aligned
+                                                   # rows, >= 512 tiles of 64x4): ragged tiles and a ragged channel chunk; an
+                                                   # unpadded call (output origin 4 pixels inside the input)
+                                                   (5, 130, 1000, 4, 1, 4, 1, 1), (6, 140, 968, 0, 1, 4, 1, 1)])
 def test_correlation_forward(torch_mod, cabi, oracle, C, H, W, pad, k, md, s1, s2):
     torch = torch_mod
     rng = np.random.default_rng(C + H)

@@ -327,10 +327,12 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
                 t[2 * k] = q.x;
                 t[2 * k + 1] = q.y;
             }
+            // (one v_fmac per term: left to itself the compiler packs the two pixels' terms into v_pk_fma_f32 -- two passes each on
+            //  gfx950, no faster -- and pays four v_pk_mov per channel to line up the odd operand pairs)
 #pragma unroll
             for (int ti = 0; ti < D; ++ti) {
-                acc[0][ti] = fmaf(a.x, t[ti], acc[0][ti]);
-                acc[1][ti] = fmaf(a.y, t[ti + 1], acc[1][ti]);
+                asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[0][ti]) : "v"(a.x), "v"(t[ti]));
+                asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[1][ti]) : "v"(a.y), "v"(t[ti + 1]));
             }
         }
     }
@@ -347,6 +349,156 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
                 float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
 #pragma unroll
                 for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[q][ti] / nelems;
+            }
+    }
+}
+
+// k == 1, strides 1, 16-byte-aligned rows, the LARGE levels (the finest pyramid level at 1080p: 288 x 496).  With one wave per
+// displacement row a workgroup is 9 waves, three fit a CU, and the finest level's 1,152 tiles of corr_forward_k1_rows2 run as
+// one full round and one half-empty one (33.7 us; the pair of both directions, exactly three rounds: 62.7).  Here a workgroup
+// is 3 waves and owns THREE displacement rows (tj = 3 g + wave) of a 64 x 4 tile, a lane owns FOUR horizontally adjacent
+// pixels: 36 running sums per lane, and per channel one 16-byte read of the first map and three of the second map's row feed
+// 36 multiply-adds (rows2: six 8-byte reads for 18).  The window a workgroup stages is the tile + 8 columns x 6 rows (the three
+// displacement rows its waves need) -- the three workgroups of a tile run on one XCD back to back and find each other's
+// lines in its L2.  ~7 workgroups per CU are resident: every tile of the finest level at once.  Channels in sequence, the same
+// fmaf per term: the same bits as every other kernel here.
+template <int MD>
+#ifndef CORR_QUAD_CC
+#define CORR_QUAD_CC 4
+#define CORR_QUAD_WAVES 4
+#endif
+#ifndef CORR_QUAD_UNROLL
+#define CORR_QUAD_UNROLL 1
+#endif
+__global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int D = 2 * MD + 1, G = 3;                                          // displacement rows per workgroup
+    static_assert(D % G == 0, "displacement rows split evenly");
+    constexpr int CCQ = CORR_QUAD_CC;                                                        // channels staged per LDS fill (measured at 32 x 288 x 496: 4 -> 26.3 us, 8 -> 27.1; five waves per SIMD spill three registers: 28.4)
+    constexpr int TW = 64, TH = 4, LW = TW + 2 * MD, LH = TH + G - 1;             // LW = 72: 18 aligned 16-byte units
+    constexpr int NT = 64 * G;
+    constexpr int UW = LW / 4, NU = CCQ * LH * UW;                       // staged 16-byte units per chunk
+    constexpr int NPT = (NU + NT - 1) / NT;
+    constexpr int FU = CCQ * TH * (TW / 4);                              // ... of the first map
+    constexpr int NF1 = (FU + NT - 1) / NT;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float tile[CCQ][LH][LW];
+    __shared__ __attribute__((aligned(16))) float f1s[CCQ][TH * TW];
+
+    // workgroups are dealt round-robin to the 8 XCDs: the three displacement-row groups of a tile are consecutive on ONE XCD
+    const int xcd = blockIdx.x % 8, kq = blockIdx.x / 8;
+    const int g = kq % (D / G), t_ = (kq / (D / G)) * 8 + xcd;
+    if (t_ >= ntiles) return;
+    const int img_ = t_ / (tiles_x * tiles_y), trem = t_ - img_ * (tiles_x * tiles_y);
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int tid = wv * 64 + lane;
+    const int tj = G * g + wv;
+    const int px = 4 * (lane & 15), py = lane >> 4;
+    const int ox = txi * TW + px, oy = tyi * TH + py;
+    const int item_ = img_ >= items.per ? 1 : 0;            // (two calls in one launch: vfi_correlation_forward_pair)
+    const int b = img_ - item_ * items.per;
+    const float* __restrict__ in1 = items.in1[item_];
+    const float* __restrict__ in2 = items.in2[item_];
+    float* __restrict__ out = items.out[item_];
+    const int64_t plane = (int64_t)h * w;
+    const float* f1 = in1 + (int64_t)b * channel * plane;
+    const float* f2 = in2 + (int64_t)b * channel * plane;
+    // window origin in input coordinates: the rows of displacement rows G g .. G g + G - 1; a multiple of 4 columns (the host
+    // checks org and MD), so with w a multiple of 4 every 16-byte unit lies wholly inside or wholly outside the frame
+    const int wy0 = tyi * TH + org - MD + G * g, wx0 = txi * TW + org - MD;
+
+    int soff[NPT], sch[NPT];
+    bool sok[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (LH * UW), rem = e - c * (LH * UW);
+        const int r = rem / UW, col = 4 * (rem - r * UW);
+        const int gy = wy0 + r, gx = wx0 + col;
+        sch[k] = c;
+        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = sok[k] ? gy * w + gx : 0;
+    }
+    int foff[NF1], fch[NF1];
+    bool fok[NF1];
+#pragma unroll
+    for (int k = 0; k < NF1; ++k) {
+        const int e = tid + k * NT;
+        const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
+        const int gy = tyi * TH + rem / (TW / 4) + org, gx = txi * TW + 4 * (rem % (TW / 4)) + org;
+        fch[k] = c;
+        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = fok[k] ? gy * w + gx : 0;
+    }
+
+    float acc[4][D];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ti = 0; ti < D; ++ti) acc[q][ti] = 0.0f;
+
+    // the next chunk's units are fetched into registers before the current chunk is multiplied
+    v4f nv[NPT], nf[NF1];
+    const v4f zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    auto fetch = [&](int c0) {
+        const int cn = min(CCQ, channel - c0);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const v4f*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+#pragma unroll
+        for (int k = 0; k < NF1; ++k)
+            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const v4f*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < channel; c0 += CCQ) {
+        const int cn = min(CCQ, channel - c0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < NU) reinterpret_cast<v4f*>(&tile[0][0][0])[e] = nv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int e = tid + k * NT;
+            if (e < FU) reinterpret_cast<v4f*>(&f1s[0][0])[e] = nf[k];
+        }
+        __syncthreads();
+        if (c0 + CCQ < channel) fetch(c0 + CCQ);
+        // (one v_fmac per term: left to itself the compiler packs pairs of them into v_pk_fma_f32 -- two passes each on gfx950, no
+        //  faster -- and pays ten register moves per channel to line the operand pairs up)
+        auto one_channel = [&](int c) {
+            const v4f a4 = *reinterpret_cast<const v4f*>(&f1s[c][py * TW + px]);
+            const v4f* row = reinterpret_cast<const v4f*>(&tile[c][py + wv][px]);
+            const v4f r0 = row[0], r1 = row[1], r2 = row[2];
+            const float a[4] = { a4.x, a4.y, a4.z, a4.w };
+            const float t[12] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w };
+#pragma unroll
+            for (int ti = 0; ti < D; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[q][ti]) : "v"(a[q]), "v"(t[q + ti]));
+        };
+#pragma unroll CORR_QUAD_UNROLL
+        for (int c = 0; c < cn; ++c) one_channel(c);
+    }
+    const float nelems = (float)channel;
+    if (oy >= oh) return;
+#ifdef CORR_QUAD_NOSTORE
+    if (acc[0][0] != 123456.789f) return;
+#endif
+    float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
+    if (ox + 3 < ow && (ow & 3) == 0) {
+        // the lane's four pixels as one 16-byte store (the host checked the output's alignment): a wave writes whole row segments
+#pragma unroll
+        for (int ti = 0; ti < D; ++ti)
+            *reinterpret_cast<v4f*>(o + (int64_t)ti * oh * ow) = v4f{acc[0][ti] / nelems, acc[1][ti] / nelems, acc[2][ti] / nelems, acc[3][ti] / nelems};
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ox + q < ow) {
+#pragma unroll
+                for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow + q] = acc[q][ti] / nelems;
             }
     }
 }
@@ -829,7 +981,12 @@ using namespace vfi;
 VFI_KNOB(long long, g_corr_big_threshold, 256);
 // ... and number of 16x4 tiles below which the one-thread-per-output kernel is used
 VFI_KNOB(long long, g_corr_flat_threshold, 64);     // measured at 1080p: 36 tiles 12 us flat vs 29 us tiled; 144 tiles 40 vs 24
-VFI_KNOB(int, g_corr_rows2, 1);                     // two pixels per lane in the tiled kernel
+VFI_KNOB(int, g_corr_rows2, 1);                     // two pixels per lane in the tiled kernel (development: 2 = four pixels per lane on every aligned level)
+// number of 64x4 tiles from which the four-pixels-per-lane kernel (three displacement rows per workgroup) is used
+#ifndef CORR_QUAD_THRESHOLD
+#define CORR_QUAD_THRESHOLD 128                      // (1080p pyramid: 64 x 144 x 248 -- 144 tiles -- 19.4 us against 21.4 with two pixels per lane; 96 x 72 x 124 -- 36 tiles -- 23.6 against 17.3)
+#endif
+VFI_KNOB(long long, g_corr_quad_threshold, CORR_QUAD_THRESHOLD);
 #ifdef VFI_DEV
 static int g_corr_mfma = 0;                         // the matrix-core kernel for the aligned levels (corr_forward_k1_mfma)
 #endif
@@ -893,6 +1050,14 @@ static int correlation_forward_items(const float* const* in1s, const float* cons
             hipLaunchKernelGGL(corr_forward_k1_mfma<4>, grid, dim3(1024, 1, 1), 0, st, items,
                                channel, h, w, oh, ow, max_displacement - pad_size);
 #endif
+        } else if (g_corr_rows2 && aligned && (out_bits & 15) == 0 &&
+                   (g_corr_rows2 == 2 || (int64_t)((ow + 63) / 64) * ((oh + 3) / 4) * batch >= g_corr_quad_threshold * nitems)) {
+            const int tiles_x = (ow + 63) / 64, tiles_y = (oh + 3) / 4;
+            const int64_t nt = (int64_t)tiles_x * tiles_y * batch;
+            if (nt > (1 << 26)) return VFI_ERR_SHAPE;
+            const unsigned wgs = (unsigned)((nt + 7) / 8) * 8 * 3;                 // whole groups of 8 XCDs x 3 displacement-row groups
+            hipLaunchKernelGGL(corr_forward_k1_quad<4>, dim3(wgs), dim3(64, 3, 1), 0, st, items,
+                               channel, h, w, oh, ow, max_displacement - pad_size, tiles_x, tiles_y, (int)nt);
         } else if (g_corr_rows2 && aligned) {
             const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
             hipLaunchKernelGGL(corr_forward_k1_rows2<4>, grid, dim3(64, 9, 1), 0, st, items,

@@ -290,7 +290,8 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     const int soff_max = 0x7fffffff - plane_bytes - cs4;      // largest scalar offset whose successor plane is still in range
     int sin = 0, sout = 0;
     auto next_in = [&]() {
-        if (sin > soff_max) {
+        if (__builtin_expect(sin > soff_max, 0)) {
+            asm volatile("; the input descriptor moves up" ::: "memory");    // (keeps this a branch: as selects it costs ten scalar instructions per channel)
             pdma = (const float*)((const char*)pdma + sin);
             din = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, 0x7fffffff, 0x00020000);
             sin = 0;
@@ -299,7 +300,8 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         if ((abl & 64) && (++alias_in & 15) == 0) sin -= 16 * cs4;
     };
     auto next_out = [&]() {                                    // (the skewed loop still stores to the plane before: offset sout - cs4 >= 0)
-        if (sout > soff_max) {
+        if (__builtin_expect(sout > soff_max, 0)) {
+            asm volatile("; the output descriptor moves up" ::: "memory");
             pout = (float*)((char*)pout + sout);
             dout = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, 0x7fffffff, 0x00020000);
             sout = 0;
@@ -307,9 +309,10 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
         sout += cs4;
         if ((abl & 128) && ++alias_out == 16) { alias_out = 1; sout -= 15 * cs4; }
     };
-    auto issue = [&](int slot) {
+    constexpr unsigned SLOT = NP * 4, RING = R * SLOT;       // bytes
+    auto issue = [&](unsigned slot) {                           // (slots by their byte offset in the ring: one scalar add per step instead of a multiply)
         const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)pdma, 0, plane_bytes, 0x00020000);
-        float* l = ring + slot * NP + wave_first * EPT;
+        float* l = ring + (slot >> 2) + wave_first * EPT;
         if (!(abl & 2)) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -323,8 +326,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     };
 #define FI_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
 #define FI_READ64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
-    auto compute = [&](int slot) {
-        const unsigned so = (unsigned)(slot * (NP * 4));
+    auto compute = [&](unsigned so) {
         const auto oplane = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, plane_bytes, 0x00020000);
         // Tap reads of pixel p come in two parts (4-byte reads: rows 0-1, then rows 2-3; 8-byte reads: row 0, then rows 1-3);
         // before pixel p is multiplied, all of its reads and the first part of pixel p + 1's have been issued: two pixels'
@@ -419,7 +421,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     // reads, multiplies pixel 1 of channel c - 1 (its taps were read before the barrier and wait in registers), issues pixel
     // 1's reads, multiplies pixel 0, and waits for pixel 1's taps: every LDS read is in flight under arithmetic of the same
     // wave, none is waited for with nothing to do (the plain order exposes the first reads after each barrier).
-    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 8 * FI_KS;      // (4-byte reads; with 8-byte reads -- 24 more registers in flight -- it measured 30 % slower; the three largest ring geometries have no registers to spare: beside the 16-byte-staging instances the K = 10 loop reloaded a register pair inside its counted pipeline)
+    constexpr bool SKEW = !B64 && FI_PX == 2 && K <= 7 * FI_KS;      // (4-byte reads; with 8-byte reads -- 24 more registers in flight -- it measured 30 % slower; the four largest ring geometries have no registers to spare: beside the 16-byte-staging instances the K = 10 loop, then the K = 8 loop reloaded registers inside their counted pipelines)
     constexpr int NQS = B64 ? 12 : 8;                        // register pairs per pixel
     v2f qa[NQS], qb[NQS];
     auto rd_all = [&](v2f (&d)[NQS], int p, unsigned so) {
@@ -471,8 +473,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), oplane, soff[p], 0, 0);
         }
     };
-    auto compute_skewed = [&](int slot, bool first) {
-        const unsigned so = (unsigned)(slot * (NP * 4));
+    auto compute_skewed = [&](unsigned so, bool first) {
         rd_all(qa, 0, so);
         if (!first) fma_store(qb, 1, pout - cs);            // pixel 1 of the previous channel
         // (at most 15 LDS reads outstanding)
@@ -489,17 +490,18 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     const bool skew = SKEW && !(abl & 32);
     // prologue: the first D windows
     const int n0 = min(D, c_end - c_begin);
-    for (int j = 0; j < n0; ++j) issue(j);
+    for (int j = 0; j < n0; ++j) issue((unsigned)j * SLOT);
     fi_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
-    int c = c_begin, slot = 0;
+    int c = c_begin;
+    unsigned slot = 0, freed = RING - SLOT;                      // the window being read; the slot every wave finished reading before the last barrier
     if constexpr (SKEW) if (skew) {
         for (; c + D <= last; ++c) {
-            issue(slot == 0 ? R - 1 : slot - 1);
+            issue(freed);
             compute_skewed(slot, c == c_begin);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");
             __builtin_amdgcn_s_barrier();
-            slot = (slot + 1 == R) ? 0 : slot + 1;
+            freed = slot; slot = (slot + SLOT == RING) ? 0u : slot + SLOT;
         }
         for (; c <= last; ++c) {
             compute_skewed(slot, c == c_begin);
@@ -507,16 +509,16 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            slot = (slot + 1 == R) ? 0 : slot + 1;
+            freed = slot; slot = (slot + SLOT == RING) ? 0u : slot + SLOT;
         }
         fma_store(qb, 1, pout - cs);                            // pixel 1 of the last channel
     }
     for (; c + D <= last; ++c) {                                // steady state: window c + D exists
-        issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
+        issue(freed);
         compute(slot);
         if (!(abl & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
         if (!(abl & 8)) __builtin_amdgcn_s_barrier();
-        slot = (slot + 1 == R) ? 0 : slot + 1;
+        freed = slot; slot = (slot + SLOT == RING) ? 0u : slot + SLOT;
     }
     for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
         compute(slot);
@@ -524,7 +526,7 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        slot = (slot + 1 == R) ? 0 : slot + 1;
+        freed = slot; slot = (slot + SLOT == RING) ? 0u : slot + SLOT;
     }
 #undef FI_READ2
 #undef FI_READ64
