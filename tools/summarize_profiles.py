@@ -129,7 +129,7 @@ if os.path.exists(os.path.join(extras, "f16_corr_pmc.json")):
     with open(os.path.join(extras, "f16_corr_pmc.json")) as fh:
         ex = json.load(fh)
     for op, block, kern, alg in (("fi196_f16", ex.get("f16", {}), "fi_forward_ori_lds_f16", 856.0 * PX),
-                                 ("corr_finest", ex.get("corr", {}), "corr_forward_k1_rows2", (2 * 32 + 81) * 4.0 * (H // 4) * (W // 4))):
+                                 ("corr_finest", ex.get("corr", {}), "corr_forward_k1_quad", (2 * 32 + 81) * 4.0 * (H // 4) * (W // 4))):
         for k, v in block.items():
             if kern in k:
                 rd, wr = v["read_bytes (EA_RDREQ x 128 B)"], v["write_bytes (WRITE_SIZE x 1024)"]
