@@ -20,6 +20,7 @@
 #include "vfi_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -259,30 +260,26 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
     // w a multiple of 4 every 16-byte unit lies wholly inside or wholly outside the frame
     const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;
 
-    // staging plans: unit e = tid + k*NT of the chunk's [CC][LH][UW] window block and of its
-    // [CC][TH][TW/4] first-map block (constant divisors)
-    int soff[NPT], sch[NPT];
-    bool sok[NPT];
+    // staging plans: unit e = tid + k*NT of the chunk's [CC][LH][UW] window block and of its [CC][TH][TW/4] first-map block
+    // (constant divisors), as byte offsets from the chunk's first plane; the loads are buffer loads through a descriptor that
+    // spans exactly the chunk's planes (corr_forward_k1_quad: units outside the frame and channels past the last return zeros)
+    unsigned soff[NPT], foff[NF1];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int e = tid + k * NT;
         const int c = e / (LH * UW), rem = e - c * (LH * UW);
         const int r = rem / UW, col = 4 * (rem - r * UW);
         const int gy = wy0 + r, gx = wx0 + col;
-        sch[k] = c;
-        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        soff[k] = sok[k] ? gy * w + gx : 0;
+        const bool ok = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = ok ? 4u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
-    int foff[NF1], fch[NF1];
-    bool fok[NF1];
 #pragma unroll
     for (int k = 0; k < NF1; ++k) {
         const int e = tid + k * NT;
         const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
         const int gy = blockIdx.y * TH + rem / (TW / 4) + org, gx = blockIdx.x * TW + 4 * (rem % (TW / 4)) + org;
-        fch[k] = c;
-        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        foff[k] = fok[k] ? gy * w + gx : 0;
+        const bool ok = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = ok ? 4u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
 
     float acc[2][D];
@@ -291,15 +288,15 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
 
     // the next chunk's units are fetched into registers before the current chunk is multiplied
     v4f nv[NPT], nf[NF1];
-    const v4f zero = { 0.0f, 0.0f, 0.0f, 0.0f };
     auto fetch = [&](int c0) {
         const int cn = min(CORR_CC_ROWS, channel - c0);
+        const int bytes = cn * (int)plane * 4;
+        const auto d2 = __builtin_amdgcn_make_buffer_rsrc((void*)(f2 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
+        const auto d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f1 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NPT; ++k)
-            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const v4f*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+        for (int k = 0; k < NPT; ++k) nv[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d2, soff[k], 0, 0));
 #pragma unroll
-        for (int k = 0; k < NF1; ++k)
-            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const v4f*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+        for (int k = 0; k < NF1; ++k) nf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d1, foff[k], 0, 0));
     };
     fetch(0);
     for (int c0 = 0; c0 < channel; c0 += CORR_CC_ROWS) {
@@ -336,21 +333,28 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
             }
         }
     }
+    // (the mean of a power-of-two channel count as a product with the exact reciprocal: corr_forward_k1_quad)
     const float nelems = (float)channel;
-    if (oy < oh && ox + 1 < ow && (ow & 1) == 0) {
-        // the lane's two pixels as one 8-byte store: a wave writes whole 128-byte row segments
-        float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
+    const bool pow2 = (channel & (channel - 1)) == 0;
+    const float inv = 1.0f / nelems;
+    auto store = [&](auto POW2) {
+        auto mean = [&](float v) { return decltype(POW2)::value ? v * inv : v / nelems; };
+        if (oy < oh && ox + 1 < ow && (ow & 1) == 0) {
+            // the lane's two pixels as one 8-byte store: a wave writes whole 128-byte row segments
+            float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
 #pragma unroll
-        for (int ti = 0; ti < D; ++ti) *reinterpret_cast<v2f*>(o + (int64_t)ti * oh * ow) = v2f{acc[0][ti] / nelems, acc[1][ti] / nelems};
-    } else {
+            for (int ti = 0; ti < D; ++ti) *reinterpret_cast<v2f*>(o + (int64_t)ti * oh * ow) = v2f{mean(acc[0][ti]), mean(acc[1][ti])};
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (ox + q < ow && oy < oh) {
-                float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+            for (int q = 0; q < 2; ++q)
+                if (ox + q < ow && oy < oh) {
+                    float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
 #pragma unroll
-                for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = acc[q][ti] / nelems;
-            }
-    }
+                    for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = mean(acc[q][ti]);
+                }
+        }
+    };
+    if (pow2) store(std::true_type{}); else store(std::false_type{});
 }
 
 // k == 1, strides 1, 16-byte-aligned rows, the LARGE levels (the finest pyramid level at 1080p: 288 x 496).  With one wave per
@@ -408,28 +412,28 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
     // checks org and MD), so with w a multiple of 4 every 16-byte unit lies wholly inside or wholly outside the frame
     const int wy0 = tyi * TH + org - MD + G * g, wx0 = txi * TW + org - MD;
 
-    int soff[NPT], sch[NPT];
-    bool sok[NPT];
+    // Staging plans: unit e = tid + k*NT of the chunk's [CC][LH][UW] window block and of its [CC][TH][TW/4] first-map block
+    // (constant divisors), as BYTE OFFSETS from the chunk's first plane.  The loads are buffer loads through a descriptor that
+    // spans exactly the chunk's planes: a unit outside the frame gets an offset out of any range, a unit of a channel past the
+    // last one falls out of the descriptor's -- both return zeros, and a chunk's fetch is five loads, no address arithmetic and
+    // no branches.  (Host: CC planes fit 31 bits.)
+    unsigned soff[NPT], foff[NF1];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int e = tid + k * NT;
         const int c = e / (LH * UW), rem = e - c * (LH * UW);
         const int r = rem / UW, col = 4 * (rem - r * UW);
         const int gy = wy0 + r, gx = wx0 + col;
-        sch[k] = c;
-        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        soff[k] = sok[k] ? gy * w + gx : 0;
+        const bool ok = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = ok ? 4u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
-    int foff[NF1], fch[NF1];
-    bool fok[NF1];
 #pragma unroll
     for (int k = 0; k < NF1; ++k) {
         const int e = tid + k * NT;
         const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
         const int gy = tyi * TH + rem / (TW / 4) + org, gx = txi * TW + 4 * (rem % (TW / 4)) + org;
-        fch[k] = c;
-        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        foff[k] = fok[k] ? gy * w + gx : 0;
+        const bool ok = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = ok ? 4u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
 
     float acc[4][D];
@@ -440,15 +444,16 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
 
     // the next chunk's units are fetched into registers before the current chunk is multiplied
     v4f nv[NPT], nf[NF1];
-    const v4f zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     auto fetch = [&](int c0) {
         const int cn = min(CCQ, channel - c0);
+        const int bytes = cn * (int)plane * 4;
+        const auto d2 = __builtin_amdgcn_make_buffer_rsrc((void*)(f2 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
+        const auto d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f1 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NPT; ++k)
-            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const v4f*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+        for (int k = 0; k < NPT; ++k) nv[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d2, soff[k], 0, 0));
 #pragma unroll
-        for (int k = 0; k < NF1; ++k)
-            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const v4f*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+        for (int k = 0; k < NF1; ++k) nf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d1, foff[k], 0, 0));
     };
     fetch(0);
     for (int c0 = 0; c0 < channel; c0 += CCQ) {
@@ -482,25 +487,30 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
 #pragma unroll CORR_QUAD_UNROLL
         for (int c = 0; c < cn; ++c) one_channel(c);
     }
-    const float nelems = (float)channel;
     if (oy >= oh) return;
-#ifdef CORR_QUAD_NOSTORE
-    if (acc[0][0] != 123456.789f) return;
-#endif
     float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
-    if (ox + 3 < ow && (ow & 3) == 0) {
-        // the lane's four pixels as one 16-byte store (the host checked the output's alignment): a wave writes whole row segments
+    // the mean: sum / (k*k*C).  For a power of two -- 32, 64, 128 of PWC-Net's five levels -- the product with the exact
+    // reciprocal is the same correctly rounded quotient (subnormal results included) at a tenth of the instructions
+    const float nelems = (float)channel;
+    const bool pow2 = (channel & (channel - 1)) == 0;
+    const float inv = 1.0f / nelems;
+    auto store = [&](auto POW2) {
+        auto mean = [&](float v) { return decltype(POW2)::value ? v * inv : v / nelems; };
+        if (ox + 3 < ow && (ow & 3) == 0) {
+            // the lane's four pixels as one 16-byte store (the host checked the output's alignment): a wave writes whole row segments
 #pragma unroll
-        for (int ti = 0; ti < D; ++ti)
-            *reinterpret_cast<v4f*>(o + (int64_t)ti * oh * ow) = v4f{acc[0][ti] / nelems, acc[1][ti] / nelems, acc[2][ti] / nelems, acc[3][ti] / nelems};
-    } else {
+            for (int ti = 0; ti < D; ++ti)
+                *reinterpret_cast<v4f*>(o + (int64_t)ti * oh * ow) = v4f{mean(acc[0][ti]), mean(acc[1][ti]), mean(acc[2][ti]), mean(acc[3][ti])};
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (ox + q < ow) {
+            for (int q = 0; q < 4; ++q)
+                if (ox + q < ow) {
 #pragma unroll
-                for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow + q] = acc[q][ti] / nelems;
-            }
-    }
+                    for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow + q] = mean(acc[q][ti]);
+                }
+        }
+    };
+    if (pow2) store(std::true_type{}); else store(std::false_type{});
 }
 
 #ifdef VFI_DEV
@@ -1039,7 +1049,8 @@ static int correlation_forward_items(const float* const* in1s, const float* cons
         const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
         // 16-byte staging needs rows, planes and bases aligned (plane = h * w floats); the tiled kernel writes a lane's two
         // pixels as one 8-byte store: an output view at an odd element offset of its storage takes the other kernels
-        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 && (in_bits & 15) == 0 && (out_bits & 7) == 0;
+        const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 && (in_bits & 15) == 0 && (out_bits & 7) == 0 &&
+                             (int64_t)h * w * 4 * (CORR_CC_ROWS + 1) < INT_MAX;      // (a chunk of planes through one buffer descriptor)
         if (small_tiles < g_corr_flat_threshold * nitems) {
             const int64_t total = (int64_t)batch * oc * oh * ow;
             hipLaunchKernelGGL(corr_forward_k1_flat<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, items,
