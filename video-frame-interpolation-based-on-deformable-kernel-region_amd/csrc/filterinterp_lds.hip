@@ -78,6 +78,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 typedef __attribute__((address_space(3))) void* fi_lptr_t;
 
+#ifdef FI_STAMPS            // development build only: where a channel step's cycles go (tools/fm_stamps.py --single)
+__device__ unsigned long long g_fi_stamps[8];       // s_memtime ticks: [0] staging issue, [1] compute, [2] vmcnt wait, [3] barrier, [4] steps
+#define FI_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define FI_T(v)
+#endif
+
 __device__ __forceinline__ int wave_min(int v) { return wave_min_i32(v); }
 __device__ __forceinline__ int wave_max(int v) { return wave_max_i32(v); }
 
@@ -490,19 +497,40 @@ __device__ __forceinline__ void fi_run_channels_lean(const float* __restrict__ i
     const bool skew = SKEW && !(abl & 32);
     // prologue: the first D windows
     const int n0 = min(D, c_end - c_begin);
+    // (The waits count staging loads only.  vmcnt also holds the FI_PX result stores of every step, in issue order, so "all but
+    //  the (D - 1) K youngest" is stricter than "window c + 1 has landed".  Round 4 counted the stores in -- (D - 1)(K + FI_PX) in the
+    //  steady state, out-of-range stores behind the prologue's windows so that the first steps see the same stream, m K + (D - 1)
+    //  FI_PX in the last steps -- bit-identical, and measured nothing: 1.056-1.066 against 1.063-1.080 ms.  The simple rule stays.)
     for (int j = 0; j < n0; ++j) issue((unsigned)j * SLOT);
     fi_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
     int c = c_begin;
     unsigned slot = 0, freed = RING - SLOT;                      // the window being read; the slot every wave finished reading before the last barrier
     if constexpr (SKEW) if (skew) {
+#ifdef FI_STAMPS
+        unsigned long long acc_i = 0, acc_c = 0, acc_w = 0, acc_b = 0, acc_n = 0;
+#endif
         for (; c + D <= last; ++c) {
+            FI_T(t0);
             issue(freed);
+            FI_T(t1);
             compute_skewed(slot, c == c_begin);
+            FI_T(t2);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");
+            FI_T(t3);
             __builtin_amdgcn_s_barrier();
+#ifdef FI_STAMPS
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            acc_i += t1 - t0; acc_c += t2 - t1; acc_w += t3 - t2; acc_b += t4 - t3; acc_n += 1;
+#endif
             freed = slot; slot = (slot + SLOT == RING) ? 0u : slot + SLOT;
         }
+#ifdef FI_STAMPS
+        if ((tid & 63) == 0) {
+            atomicAdd(&g_fi_stamps[0], acc_i); atomicAdd(&g_fi_stamps[1], acc_c); atomicAdd(&g_fi_stamps[2], acc_w);
+            atomicAdd(&g_fi_stamps[3], acc_b); atomicAdd(&g_fi_stamps[4], acc_n);
+        }
+#endif
         for (; c <= last; ++c) {
             compute_skewed(slot, c == c_begin);
             if (c < last) {
@@ -816,6 +844,16 @@ static int forward_ori_lds(const float* input1, const float* input2, const float
                            input3, output, channel, h, w, s1, s2, s3, tiles_x, tiles_y, ntiles, per_xcd, ch_per_group, kflags, blend);
     return launch_status();
 }
+
+#ifdef FI_STAMPS
+// reads the accumulators and clears them (synchronises)
+extern "C" int vfi_dev_fi_stamps(unsigned long long* host8) {
+    if (hipDeviceSynchronize() != hipSuccess) return VFI_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_fi_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return VFI_ERR_LAUNCH;
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fi_stamps), zero, sizeof(zero)) == hipSuccess ? VFI_OK : VFI_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int vfi_filterinterp_forward_ori_lds(const float* input1, const float* input2, const float* input3,
                                                  float* output, int batch, int channel, int h, int w,
