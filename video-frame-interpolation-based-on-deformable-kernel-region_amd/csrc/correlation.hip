@@ -444,7 +444,6 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
 
     // the next chunk's units are fetched into registers before the current chunk is multiplied
     v4f nv[NPT], nf[NF1];
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     auto fetch = [&](int c0) {
         const int cn = min(CCQ, channel - c0);
         const int bytes = cn * (int)plane * 4;
