@@ -582,8 +582,11 @@ def correlation_measurement(torch, cabi, wl, dev, iters=100):
         for (a0, b0), (a1, b1) in zip(wl.corr[0], wl.corr[1]):
             cabi.correlation_forward_pair(a0, b0, a1, b1, 4, 1, 4, 1, 1)
     nbytes = 2 * sum((2 * a.size(1) + 81) * 4.0 * a.size(2) * a.size(3) for a, _ in wl.corr[0])
-    one, two = hip_timed(torch, dev, singles, iters), hip_timed(torch, dev, pairs, iters)
-    return {"ten_calls_ms": round(one, 4), "five_pair_calls_ms": round(two, 4), "algorithmic_bytes": nbytes,
+    # (launches of 12-25 us each: the host has to keep ahead of the GPU, and a busy host core shows up as GPU time -- one run
+    #  of five gave 336 us for the pair calls on a box that gave 127 otherwise -- so: the best of three short runs each)
+    one = min(hip_timed(torch, dev, singles, max(10, iters // 3)) for _ in range(3))
+    two = min(hip_timed(torch, dev, pairs, max(10, iters // 3)) for _ in range(3))
+    return {"ten_calls_ms": round(one, 4), "five_pair_calls_ms": round(two, 4), "best_of": 3, "algorithmic_bytes": nbytes,
             "pair_algorithmic_GBps": round(nbytes / (two * 1e-3) / 1e9, 1)}
 
 
