@@ -324,8 +324,8 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
                 t[2 * k] = q.x;
                 t[2 * k + 1] = q.y;
             }
-            // (one v_fmac per term: left to itself the compiler packs the two pixels' terms into v_pk_fma_f32 -- two passes each on
-            //  gfx950, no faster -- and pays four v_pk_mov per channel to line up the odd operand pairs)
+            // (one v_fmac per term: left to itself the compiler packs the two pixels' terms into v_pk_fma_f32 -- 1.6 x a plain
+            //  multiply-add each on gfx950 -- and pays four v_pk_mov per channel to line up the odd operand pairs: no faster)
 #pragma unroll
             for (int ti = 0; ti < D; ++ti) {
                 asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[0][ti]) : "v"(a.x), "v"(t[ti]));
@@ -470,8 +470,7 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
         }
         __syncthreads();
         if (c0 + CCQ < channel) fetch(c0 + CCQ);
-        // (one v_fmac per term: left to itself the compiler packs pairs of them into v_pk_fma_f32 -- two passes each on gfx950, no
-        //  faster -- and pays ten register moves per channel to line the operand pairs up)
+        // (one v_fmac per term: left to itself the compiler packs pairs of them into v_pk_fma_f32 -- 1.6 x a plain multiply-add each on gfx950 -- and pays ten register moves per channel to line the operand pairs up)
         auto one_channel = [&](int c) {
             const v4f a4 = *reinterpret_cast<const v4f*>(&f1s[c][py * TW + px]);
             const v4f* row = reinterpret_cast<const v4f*>(&tile[c][py + wv][px]);
