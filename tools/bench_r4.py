@@ -101,7 +101,7 @@ def main():
                 one = timed(lambda i: cabi.correlation_forward(a0, b0, 4, 1, 4, 1, 1), args.iters)
                 two = timed(lambda i: cabi.correlation_forward_pair(a0, b0, a1, b1, 4, 1, 4, 1, 1), args.iters)
                 print("corr     level %d %s: one call %6.1f us, pair %6.1f us" % (li, tuple(a0.shape), one, two), flush=True)
-        if "multi" in what or "single" in what:
+        if "multi" in what or "single" in what or "frames" in what or "sched" in what:
             ctx = S.context(1, 196, h, w, gen).to(dev)
             filt = S.filters(1, h, w, gen).to(dev)
             frame = S.frames(1, h, w, gen).to(dev)
@@ -123,6 +123,12 @@ def main():
                 o3 = torch.empty_like(frame)
                 us = timed(lambda i: cabi.filterinterp_forward_ori(frame, projs[1], filt, o3), args.iters)
                 print("fi3      %-8s %8.1f us, %6.1f GB/s algorithmic" % (model, us, 96.0 * px / us / 1e3), flush=True)
+            if "frames" in what:
+                # the three frame warps of a direction (C = 3): three single-flow launches against the shared-window entry point
+                o3 = [torch.empty_like(frame) for _ in range(3)]
+                us1 = timed(lambda i: [cabi.filterinterp_forward_ori(frame, projs[k], filt, o3[k]) for k in range(3)], args.iters)
+                us2 = timed(lambda i: cabi.filterinterp_forward_ori_multi(frame, projs, filt, o3), args.iters)
+                print("frames   %-8s three C=3 launches %7.1f us | one shared-window call (2 + 1) %7.1f us" % (model, us1, us2), flush=True)
             if "sched" in what:
                 # both directions' context warps (three time offsets each) on two streams, as the best schedule runs them
                 from vfidkr_amd import fused
