@@ -116,7 +116,7 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
     constexpr int D = R - 1;
     constexpr int NE = FM_PX * NT;                           // evaluations per thread and channel, e = t * FM_PX + p
     constexpr int PITCH8 = 256 * S;                          // row pitch in bytes
-    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    static_assert(D >= 1 && D <= 4 && (D - 1) * K <= 63, "ring geometry");
     static_assert(3 * PITCH8 + 8 < 65536, "tap rows at immediate offsets");
     if (c_begin >= c_end) return;
     const int lane = tid & 63;
@@ -261,8 +261,28 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         oofs += cs;
     };
 #undef FM_READ_ROW
+    // The steady-state wait.  vmcnt counts the staging loads AND the NE result stores of every step, in issue order (one counter
+    // on gfx9).  Behind the loads of window c + 1 the stream holds, at the end of step c: the stores of the step that issued
+    // them, then D - 1 steps of K loads + NE stores.  Rounds 3-4 waited for vmcnt <= (D - 1) K -- with the stores in the counter
+    // that asks for part of window c + 2 as well, and with two ring slots (D = 1) for every store of the step itself.  The
+    // prologue puts NE stores whose offsets are out of range behind each of its windows, so that the first steps see the same
+    // stream as the later ones.  (In-kernel stamps had a quarter of a step in this wait.)
+#ifndef FM_COUNT_STORES
+#define FM_COUNT_STORES 1
+#endif
+    constexpr int NWAIT = (FM_COUNT_STORES && !(FM_ABL & 1)) ? (D - 1) * (K + NE) + NE : (D - 1) * K;
+    static_assert(NWAIT <= 63, "vmcnt is six bits");
     const int n0 = min(D, c_end - c_begin);
-    for (int j = 0; j < n0; ++j) issue(j);
+    {
+        const auto nowhere = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, 0, 0x00020000);      // (zero records: every offset out of range)
+        for (int j = 0; j < n0; ++j) {
+            issue(j);
+            if (FM_COUNT_STORES) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, 0x80000000u, 0, 0);
+            }
+        }
+    }
     fm_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
     int c = c_begin, slot = 0;
@@ -275,7 +295,7 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
         FM_T(t1);
         compute(slot);
         FM_T(t2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");            // window c + 1 has landed
         FM_T(t3);
         __builtin_amdgcn_s_barrier();
 #ifdef FM_STAMPS
@@ -293,7 +313,13 @@ __device__ __forceinline__ void fm_run_channels(const float* __restrict__ img, c
     for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
         compute(slot);
         if (c < last) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // behind the loads of window c + 1: m windows (m = last - c - 1 <= D - 2) and the stores of D steps -- provided
+            // window c + 1 was staged by a step of the loop above (a channel range shorter than the ring waits for everything)
+            const int m = last - c - 1;
+            if (!FM_COUNT_STORES || (FM_ABL & 1) || c - c_begin < D - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (m <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NE < 63 ? D * NE : 63) : "memory");
+            else if (m == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K + D * NE < 63 ? K + D * NE : 63) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K + D * NE < 63 ? 2 * K + D * NE : 63) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
@@ -324,7 +350,7 @@ __device__ __forceinline__ void fm_run_channels_plain(const float* __restrict__ 
     constexpr int R = (FM_RING_FLOATS / NP) < FM_RMAX ? (FM_RING_FLOATS / NP) : FM_RMAX;
     constexpr int D = R - 1;
     constexpr int NE = FM_PX * NT;                           // evaluations per thread and channel, e = t * FM_PX + p
-    static_assert(D >= 1 && (D - 1) * K <= 63, "ring geometry");
+    static_assert(D >= 1 && D <= 4 && (D - 1) * K <= 63, "ring geometry");
     if (c_begin >= c_end) return;
     // staged element e = tid + k * FM_THREADS, row pitch a multiple of the 32 LDS banks, borders replicated while
     // staging, pad elements out of the buffer's range (they cost no memory traffic): filterinterp_lds.hip
@@ -435,22 +461,40 @@ __device__ __forceinline__ void fm_run_channels_plain(const float* __restrict__ 
         oofs += cs;
     };
 #undef FM_READ2
+    // (the steady-state wait counts the result stores in: see fm_run_channels)
+    constexpr int NWAIT = FM_COUNT_STORES ? (D - 1) * (K + NE) + NE : (D - 1) * K;
+    static_assert(NWAIT <= 63, "vmcnt is six bits");
     const int n0 = min(D, c_end - c_begin);
-    for (int j = 0; j < n0; ++j) issue(j);
+    {
+        const auto nowhere = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, 0, 0x00020000);
+        for (int j = 0; j < n0; ++j) {
+            issue(j);
+            if (FM_COUNT_STORES) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, 0x80000000u, 0, 0);
+            }
+        }
+    }
     fm_wait_windows<K>(n0 - 1);                                 // the first window has landed ...
     __builtin_amdgcn_s_barrier();                               // ... in every wave
     int c = c_begin, slot = 0;
     for (; c + D <= last; ++c) {                                // steady state: window c + D exists
         issue(slot == 0 ? R - 1 : slot - 1);                    // into the slot every wave finished reading before the last barrier
         compute(slot);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * K) : "memory");      // all but the D - 1 youngest windows: c + 1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWAIT) : "memory");            // window c + 1 has landed
         __builtin_amdgcn_s_barrier();
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
     for (; c <= last; ++c) {                                    // the last D channels: nothing left to stage
         compute(slot);
         if (c < last) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // behind the loads of window c + 1: m windows (m = last - c - 1 <= D - 2) and the stores of D steps -- provided
+            // window c + 1 was staged by a step of the loop above (a channel range shorter than the ring waits for everything)
+            const int m = last - c - 1;
+            if (!FM_COUNT_STORES || (FM_ABL & 1) || c - c_begin < D - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (m <= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NE < 63 ? D * NE : 63) : "memory");
+            else if (m == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K + D * NE < 63 ? K + D * NE : 63) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K + D * NE < 63 ? 2 * K + D * NE : 63) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
