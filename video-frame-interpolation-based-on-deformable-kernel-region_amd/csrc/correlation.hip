@@ -366,41 +366,44 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2(
 // displacement rows its waves need) -- the three workgroups of a tile run on one XCD back to back and find each other's
 // lines in its L2.  ~7 workgroups per CU are resident: every tile of the finest level at once.  Channels in sequence, the same
 // fmaf per term: the same bits as every other kernel here.
+//
+// Staging: four channels per chunk by LDS-DMA (`buffer_load_dwordx4 ... lds`) into TWO LDS buffers.  The window and first-map
+// units are buffer loads through a descriptor that spans exactly the chunk's planes, with one constant byte offset per unit
+// (a unit outside the frame has an offset out of any range, a channel past the last one falls out of the descriptor's: both
+// arrive as zeros); a chunk's units go from memory straight into the buffer the previous chunk was read from, under the current
+// chunk's multiply-adds -- no staging registers, no ds_write, no address arithmetic, one barrier per chunk.  (The round's first
+// version fetched the units into registers and wrote them to LDS: 87 registers, two barriers per chunk, 24 us; this one 63
+// registers, 20.7 us at 32 x 288 x 496.)  The tap reads are asm: hipcc
+// drains vmcnt before an LDS read it can see next to an LDS-DMA target (filterinterp_lds.hip), which would wait for the chunk
+// in flight.  Same tile, same lanes, same order of the multiply-adds: the same bits.
+typedef __attribute__((address_space(3))) void* corr_lptr_t;
+#define CORR_QUAD_LDS_FLOATS (2 * (4 * 6 * 18 + 4 * 4 * 16) * 4)          // two buffers of 432 window units + 256 first-map units
 template <int MD>
-#ifndef CORR_QUAD_CC
-#define CORR_QUAD_CC 4
-#define CORR_QUAD_WAVES 4
-#endif
-#ifndef CORR_QUAD_UNROLL
-#define CORR_QUAD_UNROLL 1
-#endif
-__global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
-    CorrItems items, int channel, int h, int w, int oh, int ow, int org, int tiles_x, int tiles_y, int ntiles) {
-    constexpr int D = 2 * MD + 1, G = 3;                                          // displacement rows per workgroup
-    static_assert(D % G == 0, "displacement rows split evenly");
-    constexpr int CCQ = CORR_QUAD_CC;                                                        // channels staged per LDS fill (measured at 32 x 288 x 496: 4 -> 26.3 us, 8 -> 27.1; five waves per SIMD spill three registers: 28.4)
-    constexpr int TW = 64, TH = 4, LW = TW + 2 * MD, LH = TH + G - 1;             // LW = 72: 18 aligned 16-byte units
+__device__ __forceinline__ void corr_quad_body(
+    const CorrItems& items, int channel, int h, int w, int oh, int ow, int org, int tiles_x, int tiles_y, int ntiles, float* lds) {
+    constexpr int D = 2 * MD + 1, G = 3;
+    constexpr int CCQ = 4;
+    constexpr int TW = 64, TH = 4, LW = TW + 2 * MD, LH = TH + G - 1;
     constexpr int NT = 64 * G;
-    constexpr int UW = LW / 4, NU = CCQ * LH * UW;                       // staged 16-byte units per chunk
+    constexpr int UW = LW / 4, NU = CCQ * LH * UW;                                // 432 window units (16 bytes) per chunk
     constexpr int NPT = (NU + NT - 1) / NT;
-    constexpr int FU = CCQ * TH * (TW / 4);                              // ... of the first map
+    constexpr int FU = CCQ * TH * (TW / 4);                                       // 256 first-map units
     constexpr int NF1 = (FU + NT - 1) / NT;
+    constexpr int BUF = (NU + FU) * 4;                                            // floats per buffer: [window units][first-map units]
     typedef float v4f __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float tile[CCQ][LH][LW];
-    __shared__ __attribute__((aligned(16))) float f1s[CCQ][TH * TW];
+    static_assert(2 * BUF == CORR_QUAD_LDS_FLOATS, "the kernel's LDS array");
 
-    // workgroups are dealt round-robin to the 8 XCDs: the three displacement-row groups of a tile are consecutive on ONE XCD
     const int xcd = blockIdx.x % 8, kq = blockIdx.x / 8;
     const int g = kq % (D / G), t_ = (kq / (D / G)) * 8 + xcd;
     if (t_ >= ntiles) return;
     const int img_ = t_ / (tiles_x * tiles_y), trem = t_ - img_ * (tiles_x * tiles_y);
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
-    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int tid = wv * 64 + lane;
     const int tj = G * g + wv;
     const int px = 4 * (lane & 15), py = lane >> 4;
     const int ox = txi * TW + px, oy = tyi * TH + py;
-    const int item_ = img_ >= items.per ? 1 : 0;            // (two calls in one launch: vfi_correlation_forward_pair)
+    const int item_ = img_ >= items.per ? 1 : 0;
     const int b = img_ - item_ * items.per;
     const float* __restrict__ in1 = items.in1[item_];
     const float* __restrict__ in2 = items.in2[item_];
@@ -408,15 +411,9 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
     const int64_t plane = (int64_t)h * w;
     const float* f1 = in1 + (int64_t)b * channel * plane;
     const float* f2 = in2 + (int64_t)b * channel * plane;
-    // window origin in input coordinates: the rows of displacement rows G g .. G g + G - 1; a multiple of 4 columns (the host
-    // checks org and MD), so with w a multiple of 4 every 16-byte unit lies wholly inside or wholly outside the frame
     const int wy0 = tyi * TH + org - MD + G * g, wx0 = txi * TW + org - MD;
 
-    // Staging plans: unit e = tid + k*NT of the chunk's [CC][LH][UW] window block and of its [CC][TH][TW/4] first-map block
-    // (constant divisors), as BYTE OFFSETS from the chunk's first plane.  The loads are buffer loads through a descriptor that
-    // spans exactly the chunk's planes: a unit outside the frame gets an offset out of any range, a unit of a channel past the
-    // last one falls out of the descriptor's -- both return zeros, and a chunk's fetch is five loads, no address arithmetic and
-    // no branches.  (Host: CC planes fit 31 bits.)
+    // byte offsets of this thread's units from the chunk's first plane (out of any range: a unit outside the frame)
     unsigned soff[NPT], foff[NF1];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
@@ -435,6 +432,23 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
         const bool ok = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
         foff[k] = ok ? 4u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
+    // a wave's 64 lanes write 64 consecutive units: wave-uniform destination + lane * 16 bytes (M0).  A staging instruction whose
+    // units lie past the block's end is skipped by the waves it has nothing for and runs with a partial exec mask in the last one.
+    auto issue = [&](int c0, int buf) {
+        const int cn = min(CCQ, channel - c0);
+        const int bytes = cn * (int)plane * 4;
+        const auto d2 = __builtin_amdgcn_make_buffer_rsrc((void*)(f2 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
+        const auto d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f1 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
+        float* base = lds + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            if (tid + k * NT < NU)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(d2, (corr_lptr_t)(base + (k * NT + wv * 64) * 4), 16, soff[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NF1; ++k)
+            if (tid + k * NT < FU)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(d1, (corr_lptr_t)(base + NU * 4 + (k * NT + wv * 64) * 4), 16, foff[k], 0, 0, 0);
+    };
 
     float acc[4][D];
 #pragma unroll
@@ -442,60 +456,46 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
 #pragma unroll
         for (int ti = 0; ti < D; ++ti) acc[q][ti] = 0.0f;
 
-    // the next chunk's units are fetched into registers before the current chunk is multiplied
-    v4f nv[NPT], nf[NF1];
-    auto fetch = [&](int c0) {
-        const int cn = min(CCQ, channel - c0);
-        const int bytes = cn * (int)plane * 4;
-        const auto d2 = __builtin_amdgcn_make_buffer_rsrc((void*)(f2 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
-        const auto d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f1 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < NPT; ++k) nv[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d2, soff[k], 0, 0));
-#pragma unroll
-        for (int k = 0; k < NF1; ++k) nf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(d1, foff[k], 0, 0));
-    };
-    fetch(0);
+    const unsigned lds0 = (unsigned)(uintptr_t)(corr_lptr_t)lds;
+    const unsigned a_addr = lds0 + 4u * (unsigned)(NU * 4 + py * TW + px);                 // first map: [c][TH * TW]
+    const unsigned t_addr = lds0 + 4u * (unsigned)((py + wv) * LW + px);                   // window: [c][LH][LW]
+#define CORR_CHANNEL_TERMS(c, bo) do { \
+        v4f a4, r0, r1, r2; \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a4) : "v"(a_addr + (bo)), "n"((c) * TH * TW * 4)); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r0) : "v"(t_addr + (bo)), "n"((c) * LH * LW * 4)); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r1) : "v"(t_addr + (bo)), "n"((c) * LH * LW * 4 + 16)); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r2) : "v"(t_addr + (bo)), "n"((c) * LH * LW * 4 + 32)); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a4), "+v"(r0), "+v"(r1), "+v"(r2)); \
+        const float a_[4] = { a4.x, a4.y, a4.z, a4.w }; \
+        const float t_v[12] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w }; \
+        _Pragma("unroll") for (int ti = 0; ti < D; ++ti) \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[q][ti]) : "v"(a_[q]), "v"(t_v[q + ti])); \
+    } while (0)
+
+    issue(0, 0);
+    int buf = 0;
     for (int c0 = 0; c0 < channel; c0 += CCQ) {
         const int cn = min(CCQ, channel - c0);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NPT; ++k) {
-            const int e = tid + k * NT;
-            if (e < NU) reinterpret_cast<v4f*>(&tile[0][0][0])[e] = nv[k];
-        }
-#pragma unroll
-        for (int k = 0; k < NF1; ++k) {
-            const int e = tid + k * NT;
-            if (e < FU) reinterpret_cast<v4f*>(&f1s[0][0])[e] = nf[k];
-        }
-        __syncthreads();
-        if (c0 + CCQ < channel) fetch(c0 + CCQ);
-        // (one v_fmac per term: left to itself the compiler packs pairs of them into v_pk_fma_f32 -- 1.6 x a plain multiply-add each on gfx950 -- and pays ten register moves per channel to line the operand pairs up)
-        auto one_channel = [&](int c) {
-            const v4f a4 = *reinterpret_cast<const v4f*>(&f1s[c][py * TW + px]);
-            const v4f* row = reinterpret_cast<const v4f*>(&tile[c][py + wv][px]);
-            const v4f r0 = row[0], r1 = row[1], r2 = row[2];
-            const float a[4] = { a4.x, a4.y, a4.z, a4.w };
-            const float t[12] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w };
-#pragma unroll
-            for (int ti = 0; ti < D; ++ti)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc[q][ti]) : "v"(a[q]), "v"(t[q + ti]));
-        };
-#pragma unroll CORR_QUAD_UNROLL
-        for (int c = 0; c < cn; ++c) one_channel(c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's units of the chunk have landed ...
+        __builtin_amdgcn_s_barrier();                           // ... everybody's have, and everybody is done with the other buffer
+        if (c0 + CCQ < channel) issue(c0 + CCQ, buf ^ 1);
+        const unsigned bo = (unsigned)(buf * BUF * 4);
+        CORR_CHANNEL_TERMS(0, bo);
+        if (cn > 1) CORR_CHANNEL_TERMS(1, bo);
+        if (cn > 2) CORR_CHANNEL_TERMS(2, bo);
+        if (cn > 3) CORR_CHANNEL_TERMS(3, bo);
+        buf ^= 1;
     }
+#undef CORR_CHANNEL_TERMS
+    static_assert(CCQ == 4, "four channels per chunk");
     if (oy >= oh) return;
     float* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox;
-    // the mean: sum / (k*k*C).  For a power of two -- 32, 64, 128 of PWC-Net's five levels -- the product with the exact
-    // reciprocal is the same correctly rounded quotient (subnormal results included) at a tenth of the instructions
     const float nelems = (float)channel;
     const bool pow2 = (channel & (channel - 1)) == 0;
     const float inv = 1.0f / nelems;
     auto store = [&](auto POW2) {
         auto mean = [&](float v) { return decltype(POW2)::value ? v * inv : v / nelems; };
         if (ox + 3 < ow && (ow & 3) == 0) {
-            // the lane's four pixels as one 16-byte store (the host checked the output's alignment): a wave writes whole row segments
 #pragma unroll
             for (int ti = 0; ti < D; ++ti)
                 *reinterpret_cast<v4f*>(o + (int64_t)ti * oh * ow) = v4f{mean(acc[0][ti]), mean(acc[1][ti]), mean(acc[2][ti]), mean(acc[3][ti])};
@@ -510,6 +510,17 @@ __global__ __launch_bounds__(192, CORR_QUAD_WAVES) void corr_forward_k1_quad(
     };
     if (pow2) store(std::true_type{}); else store(std::false_type{});
 }
+
+// (the body is a device function: its inline assembly must not be instantiated by the host pass)
+template <int MD>
+__global__ __launch_bounds__(192, 5) void corr_forward_k1_quad(
+    CorrItems items, int channel, int h, int w, int oh, int ow, int org, int tiles_x, int tiles_y, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[CORR_QUAD_LDS_FLOATS];  // ONE array (see above)
+    corr_quad_body<MD>(items, channel, h, w, oh, ow, org, tiles_x, tiles_y, ntiles, lds);
+}
+
+// (explicit: hipcc 7.2 leaves the host stub of a kernel template undefined when its only launch sits in a branch it folds away)
+template __global__ void corr_forward_k1_quad<4>(CorrItems, int, int, int, int, int, int, int, int, int);
 
 #ifdef VFI_DEV
 // DEVELOPMENT BUILDS ONLY (measured, slower: see the end of this comment).
