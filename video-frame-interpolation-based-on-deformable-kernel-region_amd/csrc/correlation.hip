@@ -744,28 +744,25 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2_f16(
     const __half* f2 = in2 + (int64_t)b * channel * plane;
     const int wy0 = blockIdx.y * TH + org - MD, wx0 = blockIdx.x * TW + org - MD;
 
-    int soff[NPT], sch[NPT];
-    bool sok[NPT];
+    // staging plans as byte offsets from the chunk's first plane; buffer loads through a descriptor that spans exactly the chunk's
+    // planes (corr_forward_k1_quad: units outside the frame and channels past the last one arrive as zeros)
+    unsigned soff[NPT], foff[NF1];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int e = tid + k * NT;
         const int c = e / (LH * UW), rem = e - c * (LH * UW);
         const int r = rem / UW, col = 4 * (rem - r * UW);
         const int gy = wy0 + r, gx = wx0 + col;
-        sch[k] = c;
-        sok[k] = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        soff[k] = sok[k] ? gy * w + gx : 0;
+        const bool ok = e < NU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        soff[k] = ok ? 2u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
-    int foff[NF1], fch[NF1];
-    bool fok[NF1];
 #pragma unroll
     for (int k = 0; k < NF1; ++k) {
         const int e = tid + k * NT;
         const int c = e / (TH * (TW / 4)), rem = e - c * (TH * (TW / 4));
         const int gy = blockIdx.y * TH + rem / (TW / 4) + org, gx = blockIdx.x * TW + 4 * (rem % (TW / 4)) + org;
-        fch[k] = c;
-        fok[k] = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        foff[k] = fok[k] ? gy * w + gx : 0;
+        const bool ok = e < FU && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        foff[k] = ok ? 2u * (unsigned)(c * (int)plane + gy * w + gx) : 0x80000000u;
     }
 
     float acc[2][D];
@@ -773,15 +770,16 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2_f16(
     for (int ti = 0; ti < D; ++ti) { acc[0][ti] = 0.0f; acc[1][ti] = 0.0f; }
 
     uint2 nv[NPT], nf[NF1];
-    const uint2 zero = make_uint2(0u, 0u);
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
     auto fetch = [&](int c0) {
         const int cn = min(CORR_CC_ROWS, channel - c0);
+        const int bytes = cn * (int)plane * 2;
+        const auto d2 = __builtin_amdgcn_make_buffer_rsrc((void*)(f2 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
+        const auto d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(f1 + (int64_t)c0 * plane), 0, bytes, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NPT; ++k)
-            nv[k] = (sok[k] && sch[k] < cn) ? *reinterpret_cast<const uint2*>(f2 + (int64_t)(c0 + sch[k]) * plane + soff[k]) : zero;
+        for (int k = 0; k < NPT; ++k) { const v2u_ v = __builtin_amdgcn_raw_buffer_load_b64(d2, soff[k], 0, 0); nv[k] = make_uint2(v.x, v.y); }
 #pragma unroll
-        for (int k = 0; k < NF1; ++k)
-            nf[k] = (fok[k] && fch[k] < cn) ? *reinterpret_cast<const uint2*>(f1 + (int64_t)(c0 + fch[k]) * plane + foff[k]) : zero;
+        for (int k = 0; k < NF1; ++k) { const v2u_ v = __builtin_amdgcn_raw_buffer_load_b64(d1, foff[k], 0, 0); nf[k] = make_uint2(v.x, v.y); }
     };
     fetch(0);
     for (int c0 = 0; c0 < channel; c0 += CORR_CC_ROWS) {
@@ -817,14 +815,20 @@ __global__ __launch_bounds__(64 * (2 * MD + 1)) void corr_forward_k1_rows2_f16(
             }
         }
     }
+    // (the mean of a power-of-two channel count as a product with the exact reciprocal: the same real number, rounded to half once)
     const float nelems = (float)channel;
+    const bool pow2 = (channel & (channel - 1)) == 0;
+    const float inv = 1.0f / nelems;
+    auto store = [&](auto POW2) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-        if (ox + q < ow && oy < oh) {
-            __half* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
+        for (int q = 0; q < 2; ++q)
+            if (ox + q < ow && oy < oh) {
+                __half* o = out + ((int64_t)b * (D * D) + tj * D) * oh * ow + (int64_t)oy * ow + ox + q;
 #pragma unroll
-            for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = __float2half_rn(acc[q][ti] / nelems);
-        }
+                for (int ti = 0; ti < D; ++ti) o[(int64_t)ti * oh * ow] = __float2half_rn(decltype(POW2)::value ? acc[q][ti] * inv : acc[q][ti] / nelems);
+            }
+    };
+    if (pow2) store(std::true_type{}); else store(std::false_type{});
 }
 
 // half inputs and output, the reference's `scalar_t = at::Half` instantiation (correlation_cuda_kernel.cu:386,403):
@@ -1143,7 +1147,8 @@ extern "C" int vfi_correlation_forward_f16(const void* input1, const void* input
         // PWC-Net's configuration on frames whose rows are 8-byte aligned, enough tiles to fill the chip: the tiled kernel
         const int64_t small_tiles = (int64_t)((ow + 15) / 16) * ((oh + 3) / 4) * batch;
         const bool aligned = (w & 3) == 0 && ((max_displacement - pad_size) & 3) == 0 &&
-                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 7) == 0;
+                             ((reinterpret_cast<uintptr_t>(input1) | reinterpret_cast<uintptr_t>(input2)) & 7) == 0 &&
+                             (int64_t)h * w * 2 * (CORR_CC_ROWS + 1) < INT_MAX;      // (a chunk of planes through one buffer descriptor)
         // (measured at the 1080p pyramid: 144 such tiles 27 us tiled vs 21 us one thread per output; 576 tiles 33 vs 101)
         if (aligned && small_tiles >= 4 * g_corr_flat_threshold) {
             const dim3 grid((ow + 31) / 32, (oh + 3) / 4, batch);
