@@ -365,3 +365,26 @@ def test_filterinterp_channel_planes_farther_apart_than_a_descriptor_spans(torch
     assert np.all(g == -7.0)
     del src, dst
     torch.cuda.empty_cache()
+
+
+def test_correlation_kernels_agree_on_random_shapes(torch_mod, cabi):
+    """PWC-Net's configuration on random shapes: the aligned path (the four-pixel kernel for large levels, the two-pixel one below)
+    and the kernels that take over when the inputs sit at an odd element offset of their storage sum the channels in the same
+    order -- same bits; the pair entry equals two single calls.  (tools/corr_soak.py runs more of these.)"""
+    torch = torch_mod
+    g = torch.Generator().manual_seed(5)
+    for case in range(14):
+        b = int(torch.randint(1, 3, (1,), generator=g))
+        c = int(torch.randint(1, 70, (1,), generator=g))
+        h = int(torch.randint(9, 300, (1,), generator=g))
+        w = 4 * int(torch.randint(4, 260, (1,), generator=g))
+        pad = 4 if case % 5 else 0
+        n = b * c * h * w
+        s1, s2 = torch.randn(n + 1, generator=g).to("cuda:0"), torch.randn(n + 1, generator=g).to("cuda:0")
+        u1, u2 = s1[1:].view(b, c, h, w), s2[1:].view(b, c, h, w)                  # 4 bytes off a 16-byte boundary
+        a1, a2 = u1.clone(), u2.clone()                                             # the same values, aligned
+        ref = cabi.correlation_forward(u1, u2, pad, 1, 4, 1, 1)
+        out = cabi.correlation_forward(a1, a2, pad, 1, 4, 1, 1)
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (b, c, h, w, pad)
+        pa, pb = cabi.correlation_forward_pair(a1, a2, a2, a1, pad, 1, 4, 1, 1)
+        assert torch.equal(pa, out) and torch.equal(pb, cabi.correlation_forward(a2, a1, pad, 1, 4, 1, 1)), (b, c, h, w, pad)
